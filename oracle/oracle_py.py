@@ -1,0 +1,190 @@
+"""ctypes driver for oracle/build/libekf_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Mirrors the public surface of the reference's TightlyCoupledEKF
+(include/ekf_vio/TightlyCoupledEKF.h:27-68) over the C++ restatement in ekf_oracle.hpp.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "libekf_oracle.so")
+_lib = None
+
+BASE = 22
+
+
+def build_oracle(force=False):
+    """Compile the oracle with g++ (make -C oracle)."""
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.hpp", "ekf_oracle_capi.cpp", "klt_oracle.cpp", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def oracle_lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(lib):
+    vp, i32, u8p, ip = C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int)
+    for pre, ct in (("orc32", C.c_float), ("orc64", C.c_double)):
+        tp = C.POINTER(ct)
+        g = lambda name: getattr(lib, pre + "_" + name)
+        g("create").restype = vp
+        g("create").argtypes = [C.c_double, C.c_double, C.c_double, i32]
+        g("destroy").argtypes = [vp]
+        g("num_features").argtypes = [vp]
+        g("dim").argtypes = [vp]
+        g("add_features").argtypes = [vp, tp, i32]
+        g("process").argtypes = [vp, ct]
+        g("update").argtypes = [vp, tp, tp, u8p]
+        g("update").restype = i32
+        g("linearize").argtypes = [vp, ct, tp]
+        g("convolve_base").argtypes = [vp, tp, ct, tp]
+        g("convolve_feature").argtypes = [vp, tp, tp, ct, tp]
+        g("process_noise_diag").argtypes = [vp, ct, tp]
+        g("measurement_map").argtypes = [vp, u8p, ip]
+        g("measurement_map").restype = i32
+        g("get_state").argtypes = [vp, tp, tp, tp, u8p, tp]
+        g("set_state").argtypes = [vp, i32, tp, tp, tp, u8p, tp]
+        g("check_sigma").argtypes = [vp, tp, tp]
+        g("time_steps").argtypes = [vp, i32, ct, tp, tp, u8p]
+        g("time_steps").restype = C.c_double
+    lib.orc_set_threads.argtypes = [i32]
+    lib.orc_max_threads.restype = i32
+
+
+def set_threads(t):
+    oracle_lib().orc_set_threads(int(t))
+
+
+def max_threads():
+    return int(oracle_lib().orc_max_threads())
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+class OracleFilter:
+    """CPU restatement of TightlyCoupledEKF.  dtype=np.float32 is the reference
+    precision; np.float64 is the yardstick."""
+
+    def __init__(self, dtype=np.float32, depth=0.5, depth_var=100.0, homog_var=1e-5, emulate_static_cache=True):
+        self.lib = oracle_lib()
+        self.dtype = np.dtype(dtype)
+        self.pre = "orc32" if self.dtype == np.float32 else "orc64"
+        self.ct = C.c_float if self.dtype == np.float32 else C.c_double
+        self.h = C.c_void_p(self._f("create")(depth, depth_var, homog_var, int(bool(emulate_static_cache))))
+
+    def _f(self, name):
+        return getattr(self.lib, self.pre + "_" + name)
+
+    def close(self):
+        if self.h:
+            self._f("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _arr(self, a):
+        return np.ascontiguousarray(a, dtype=self.dtype)
+
+    @property
+    def num_features(self):
+        return int(self._f("num_features")(self.h))
+
+    @property
+    def dim(self):
+        return int(self._f("dim")(self.h))
+
+    def add_new_features(self, uv):
+        uv = self._arr(uv).reshape(-1, 2)
+        self._f("add_features")(self.h, _p(uv, self.ct), uv.shape[0])
+
+    def process(self, dt):
+        self._f("process")(self.h, self.ct(dt))
+
+    def update(self, z, R, passed):
+        N = self.num_features
+        z = self._arr(z).reshape(N, 2)
+        R = self._arr(R).reshape(N, 4)
+        p = np.ascontiguousarray(passed, dtype=np.uint8).reshape(N)
+        return int(self._f("update")(self.h, _p(z, self.ct), _p(R, self.ct), _p(p, C.c_uint8)))
+
+    def linearize(self, dt):
+        n = self.dim
+        F = np.zeros((n, n), dtype=self.dtype)  # filled column-major
+        self._f("linearize")(self.h, self.ct(dt), _p(F, self.ct))
+        return F.T.copy()  # -> F[row, col]
+
+    def convolve_base_state(self, mu, dt):
+        mu = self._arr(mu)
+        out = np.zeros(BASE, dtype=self.dtype)
+        self._f("convolve_base")(self.h, _p(mu, self.ct), self.ct(dt), _p(out, self.ct))
+        return out
+
+    def convolve_feature(self, base, feat, dt):
+        base, feat = self._arr(base), self._arr(feat)
+        out = np.zeros(3, dtype=self.dtype)
+        self._f("convolve_feature")(self.h, _p(base, self.ct), _p(feat, self.ct), self.ct(dt), _p(out, self.ct))
+        return out
+
+    def process_noise_diag(self, dt):
+        q = np.zeros(self.dim, dtype=self.dtype)
+        self._f("process_noise_diag")(self.h, self.ct(dt), _p(q, self.ct))
+        return q
+
+    def form_feature_measurement_map(self, measured):
+        m = np.ascontiguousarray(measured, dtype=np.uint8)
+        idx = np.zeros(2 * len(m) + 1, dtype=np.int32)
+        k = self._f("measurement_map")(self.h, _p(m, C.c_uint8), _p(idx, C.c_int))
+        return idx[:k].copy()
+
+    def get_state(self):
+        N, n = self.num_features, self.dim
+        base = np.zeros(BASE, self.dtype)
+        feat = np.zeros((N, 3), self.dtype)
+        klt = np.zeros((N, 2), self.dtype)
+        dele = np.zeros(N, np.uint8)
+        sig = np.zeros((n, n), self.dtype)
+        self._f("get_state")(self.h, _p(base, self.ct), _p(feat, self.ct), _p(klt, self.ct), _p(dele, C.c_uint8),
+                             _p(sig, self.ct))
+        return dict(base_mu=base, feat_mu=feat, last_klt=klt, del_flag=dele, Sigma=sig.T.copy())
+
+    def set_state(self, st):
+        base = self._arr(st["base_mu"])
+        feat = self._arr(st["feat_mu"]).reshape(-1, 3)
+        N = feat.shape[0]
+        klt = self._arr(st["last_klt"]).reshape(N, 2)
+        dele = np.ascontiguousarray(st["del_flag"], dtype=np.uint8).reshape(N)
+        sig = np.ascontiguousarray(np.asarray(st["Sigma"], dtype=self.dtype).T)  # column-major
+        self._f("set_state")(self.h, N, _p(base, self.ct), _p(feat, self.ct), _p(klt, self.ct), _p(dele, C.c_uint8),
+                             _p(sig, self.ct))
+
+    def check_sigma(self):
+        a, b = self.ct(0), self.ct(0)
+        self._f("check_sigma")(self.h, C.byref(a), C.byref(b))
+        return float(a.value), float(b.value)
+
+    def time_steps(self, steps, dt, z, R, passed):
+        N = self.num_features
+        z = self._arr(z).reshape(N, 2)
+        R = self._arr(R).reshape(N, 4)
+        p = np.ascontiguousarray(passed, dtype=np.uint8).reshape(N)
+        return float(self._f("time_steps")(self.h, int(steps), self.ct(dt), _p(z, self.ct), _p(R, self.ct),
+                                           _p(p, C.c_uint8)))
