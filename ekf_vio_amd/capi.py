@@ -1,0 +1,86 @@
+"""ctypes binding of libekfvio_hip.so (include/ekfvio.h).  No fallback: a missing or
+unloadable library raises; nothing in this package computes on the CPU."""
+import ctypes as C
+import os
+
+from . import _build
+
+OK, EINVAL, ENUMERIC, ECAPACITY, EDEVICE, ESTATE = range(6)
+_ERR = {EINVAL: "EKFVIO_EINVAL", ENUMERIC: "EKFVIO_ENUMERIC", ECAPACITY: "EKFVIO_ECAPACITY",
+        EDEVICE: "EKFVIO_EDEVICE", ESTATE: "EKFVIO_ESTATE"}
+PREDICT_STRUCTURED, PREDICT_DENSE = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [("max_features", C.c_int32), ("default_point_depth", C.c_float),
+                ("default_point_depth_variance", C.c_float), ("default_point_homogenous_variance", C.c_float),
+                ("predict_mode", C.c_int32), ("klt_window_size", C.c_int32), ("klt_max_pyramid_level", C.c_int32),
+                ("klt_max_iterations", C.c_int32), ("klt_epsilon", C.c_float), ("klt_min_eigen", C.c_float),
+                ("kill_pad", C.c_int32), ("max_image_width", C.c_int32), ("max_image_height", C.c_int32),
+                ("use_principal_point", C.c_int32)]
+
+
+class EkfvioError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s %s" % (_ERR.get(code, str(code)), msg))
+        self.code = code
+
+
+# every symbol include/ekfvio.h declares
+SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_reset", "ekfvio_last_error",
+           "ekfvio_add_features", "ekfvio_process", "ekfvio_linearize", "ekfvio_update", "ekfvio_measurement_map",
+           "ekfvio_num_features", "ekfvio_dim", "ekfvio_get_base_mu", "ekfvio_get_features", "ekfvio_get_sigma",
+           "ekfvio_get_feature_cov", "ekfvio_get_depth_variance", "ekfvio_check_sigma", "ekfvio_set_state",
+           "ekfvio_klt_push_frame", "ekfvio_klt_track", "ekfvio_klt_track_points", "ekfvio_step_image", "ekfvio_imu",
+           "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
+           "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
+           "ekfvio_test_gemm", "ekfvio_test_cholesky_solve"]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load(build_if_missing=True):
+    """Loads the HIP library (building it with hipcc first if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB_PATH):
+        if not build_if_missing:
+            raise FileNotFoundError(_build.LIB_PATH + " not built; run python -m ekf_vio_amd._build")
+        _build.build()
+    lib = C.CDLL(_build.LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    fp, u8p, ip = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    sig = {
+        "ekfvio_default_config": [C.POINTER(Config)],
+        "ekfvio_create": [C.POINTER(Config), C.c_int, vp, C.POINTER(vp)],
+        "ekfvio_destroy": [vp], "ekfvio_reset": [vp],
+        "ekfvio_add_features": [vp, fp, i32], "ekfvio_process": [vp, f32], "ekfvio_linearize": [vp, f32, fp],
+        "ekfvio_update": [vp, fp, fp, u8p, i32], "ekfvio_measurement_map": [vp, u8p, i32, ip, ip],
+        "ekfvio_num_features": [vp], "ekfvio_dim": [vp], "ekfvio_get_base_mu": [vp, fp],
+        "ekfvio_get_features": [vp, fp, fp, u8p], "ekfvio_get_sigma": [vp, fp, i32],
+        "ekfvio_get_feature_cov": [vp, i32, fp], "ekfvio_get_depth_variance": [vp, i32, fp],
+        "ekfvio_check_sigma": [vp, fp, fp], "ekfvio_set_state": [vp, i32, fp, fp, fp, u8p, fp, i32],
+        "ekfvio_klt_push_frame": [vp, u8p, i32, i32, i32, fp], "ekfvio_klt_track": [vp, fp, fp, u8p],
+        "ekfvio_klt_track_points": [vp, fp, fp, i32, fp, u8p],
+        "ekfvio_step_image": [vp, C.c_double, u8p, i32, i32, i32, fp], "ekfvio_imu": [vp, C.c_double, fp, fp],
+        "ekfvio_upload_measurements": [vp, i32, fp, fp, u8p], "ekfvio_run_uploaded": [vp, i32, i32, f32],
+        "ekfvio_synchronize": [vp], "ekfvio_profile_enable": [vp, i32], "ekfvio_profile_reset": [vp],
+        "ekfvio_profile_count": [], "ekfvio_profile_name": [i32],
+        "ekfvio_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
+        "ekfvio_test_gemm": [vp, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32],
+        "ekfvio_test_cholesky_solve": [vp, i32, i32, fp, fp, fp, fp, ip],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.ekfvio_last_error.argtypes = [vp]
+    lib.ekfvio_last_error.restype = C.c_char_p
+    lib.ekfvio_profile_name.restype = C.c_char_p
+    _lib = lib
+    return lib

@@ -1,0 +1,461 @@
+// ekf_vio_amd/csrc/api.hip — the C-ABI of libekfvio_hip.so (include/ekfvio.h).
+// Host-side orchestration only: every numeric step is a HIP kernel on the handle's stream.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+#define HIPC(f, expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (f)->last_error = std::string(#expr) + ": " + hipGetErrorString(e__);                  \
+            return EKFVIO_EDEVICE;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+template <class T>
+hipError_t dev_alloc(T** p, size_t count) {
+    hipError_t e = hipMalloc((void**)p, sizeof(T) * (count ? count : 1));
+    if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(T) * (count ? count : 1));
+    return e;
+}
+
+__global__ void init_sigma_kernel(float* P, int ld) {
+    // initializeBaseState (TightlyCoupledEKF.cpp:23-56): diag [0x7, 30x9, 0.5x6]
+    int i = threadIdx.x;
+    if (i >= 7 && i <= 15) P[(size_t)i * ld + i] = 30.f;
+    if (i >= 16 && i <= 21) P[(size_t)i * ld + i] = 0.5f;
+}
+
+// addNewFeatures (:58-94): new rows/columns are zero, new diagonal [hv, hv, dv]
+__global__ void add_features_kernel(float* P, int ld, int n_old, int k, float hv, float dv, float* mu, float* last_klt,
+                                    uint8_t* del_flag, const float* uv, int N_old, float inv_depth) {
+    const int n_new = n_old + 3 * k;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)3 * k * n_new;
+         e += (size_t)gridDim.x * blockDim.x) {
+        int q = e / n_new;      // which new row/col
+        int i = e % n_new;
+        int s = n_old + q;
+        P[(size_t)s * ld + i] = (i == s) ? ((q % 3 == 2) ? dv : hv) : 0.f;  // new column
+        P[(size_t)i * ld + s] = (i == s) ? ((q % 3 == 2) ? dv : hv) : 0.f;  // new row
+    }
+    for (int fidx = blockIdx.x * blockDim.x + threadIdx.x; fidx < k; fidx += gridDim.x * blockDim.x) {
+        float u = uv[2 * fidx], v = uv[2 * fidx + 1];
+        mu[n_old + 3 * fidx] = u;
+        mu[n_old + 3 * fidx + 1] = v;
+        mu[n_old + 3 * fidx + 2] = inv_depth;
+        last_klt[2 * (N_old + fidx)] = u;
+        last_klt[2 * (N_old + fidx) + 1] = v;
+        del_flag[N_old + fidx] = 0;
+    }
+}
+
+int count_rows(const uint8_t* pass, int N) {
+    int c = 0;
+    for (int i = 0; i < N; i++) c += pass[i] ? 1 : 0;
+    return 2 * c;
+}
+}  // namespace
+
+static const char* kProfNames[PC_COUNT] = {"linearize",   "predict_structured", "gemm_predict", "gather",
+                                           "cholesky",    "solve",              "gemm_update",  "update_misc",
+                                           "klt_pyramid", "klt_track"};
+
+extern "C" {
+
+int ekfvio_default_config(ekfvio_config* c) {
+    if (!c) return EKFVIO_EINVAL;
+    c->max_features = 100;                        // D_NUM_FEATURES
+    c->default_point_depth = 0.5f;                // D_DEFAULT_POINT_DEPTH
+    c->default_point_depth_variance = 100.f;      // D_DEFAULT_POINT_DEPTH_VARIANCE
+    c->default_point_homogenous_variance = 1e-5f; // D_DEFAULT_POINT_HOMOGENOUS_VARIANCE
+    c->predict_mode = EKFVIO_PREDICT_STRUCTURED;
+    c->klt_window_size = 21;
+    c->klt_max_pyramid_level = 3;
+    c->klt_max_iterations = 30;
+    c->klt_epsilon = 0.01f;
+    c->klt_min_eigen = 1e-4f;
+    c->kill_pad = 11;
+    c->max_image_width = 640;
+    c->max_image_height = 480;
+    c->use_principal_point = 0;
+    return EKFVIO_OK;
+}
+
+int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out) {
+    if (!cfg || !out || cfg->max_features < 0) return EKFVIO_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return EKFVIO_EDEVICE;
+    ekfvio_filter* f = new ekfvio_filter();
+    f->cfg = *cfg;
+    f->device = device;
+    *out = f;
+    HIPC(f, hipSetDevice(device));
+    if (stream) {
+        f->stream = (hipStream_t)stream;
+    } else {
+        HIPC(f, hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+        f->own_stream = true;
+    }
+    const int maxf = cfg->max_features;
+    f->n_cap = EKF_BASE + 3 * maxf;
+    f->ldp = round_up(f->n_cap, 64);
+    f->m_cap = round_up(2 * maxf > 0 ? 2 * maxf : 1, 64);
+    const size_t pp = (size_t)f->ldp * f->ldp, pm = (size_t)f->ldp * f->m_cap, mm = (size_t)f->m_cap * f->m_cap;
+    HIPC(f, dev_alloc(&f->mu, f->ldp));
+    HIPC(f, dev_alloc(&f->mu_next, f->ldp));
+    HIPC(f, dev_alloc(&f->last_klt, 2 * (size_t)maxf));
+    HIPC(f, dev_alloc(&f->del_flag, (size_t)maxf));
+    HIPC(f, dev_alloc(&f->P, pp));
+    HIPC(f, dev_alloc(&f->P2, pp));
+    HIPC(f, dev_alloc(&f->FA, EKF_BASE * EKF_BASE));
+    HIPC(f, dev_alloc(&f->FB, 27 * (size_t)maxf));
+    HIPC(f, dev_alloc(&f->FD, 9 * (size_t)maxf));
+    HIPC(f, dev_alloc(&f->Fdense, pp));
+    HIPC(f, dev_alloc(&f->idx, (size_t)f->m_cap));
+    HIPC(f, dev_alloc(&f->zmeas, 2 * (size_t)maxf));
+    HIPC(f, dev_alloc(&f->Rmeas, 4 * (size_t)maxf));
+    HIPC(f, dev_alloc(&f->pass, (size_t)maxf));
+    HIPC(f, dev_alloc(&f->yres, (size_t)f->m_cap));
+    HIPC(f, dev_alloc(&f->Rm, 2 * (size_t)f->m_cap));
+    HIPC(f, dev_alloc(&f->S, mm));
+    HIPC(f, dev_alloc(&f->L, mm));
+    HIPC(f, dev_alloc(&f->Linv, 64 * (size_t)f->m_cap));
+    HIPC(f, dev_alloc(&f->Km, pm));
+    HIPC(f, dev_alloc(&f->Wt, pm));
+    HIPC(f, dev_alloc(&f->Gm, pm));
+    HIPC(f, dev_alloc(&f->info, 4));
+    HIPC(f, hipHostMalloc((void**)&f->h_info, 4 * sizeof(int), hipHostMallocDefault));
+    HIPC(f, hipEventCreate(&f->ev0));
+    HIPC(f, hipEventCreate(&f->ev1));
+    int rc = klt_alloc(f);
+    if (rc != EKFVIO_OK) return rc;
+    return ekfvio_reset(f);
+}
+
+int ekfvio_destroy(ekfvio_filter* f) {
+    if (!f) return EKFVIO_EINVAL;
+    hipSetDevice(f->device);
+    hipStreamSynchronize(f->stream);
+    void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
+                    f->idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->S,  f->L,  f->Linv, f->Km,
+                    f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (f->h_info) hipHostFree(f->h_info);
+    klt_free(f);
+    if (f->ev0) hipEventDestroy(f->ev0);
+    if (f->ev1) hipEventDestroy(f->ev1);
+    if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
+    delete f;
+    return EKFVIO_OK;
+}
+
+const char* ekfvio_last_error(const ekfvio_filter* f) { return f ? f->last_error.c_str() : "null handle"; }
+
+int ekfvio_reset(ekfvio_filter* f) {
+    if (!f) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    f->N = 0;
+    f->n = EKF_BASE;
+    HIPC(f, hipMemsetAsync(f->P, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
+    HIPC(f, hipMemsetAsync(f->mu, 0, sizeof(float) * f->ldp, f->stream));
+    const float one = 1.f;
+    HIPC(f, hipMemcpyAsync(f->mu + 3, &one, sizeof(float), hipMemcpyHostToDevice, f->stream));
+    hipLaunchKernelGGL(init_sigma_kernel, dim3(1), dim3(32), 0, f->stream, f->P, f->ldp);
+    HIPC(f, hipMemsetAsync(f->info, 0, 4 * sizeof(int), f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    f->have_stamp = false;
+    f->frames[0].valid = f->frames[1].valid = false;
+    return EKFVIO_OK;
+}
+
+int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count) {
+    if (!f || count < 0 || (count > 0 && !uv)) return EKFVIO_EINVAL;
+    if (count == 0) return EKFVIO_OK;  // reference: early return (:59)
+    if (f->N + count > f->cfg.max_features) return EKFVIO_ECAPACITY;
+    HIPC(f, hipSetDevice(f->device));
+    // stage uv through the (free between updates) zmeas buffer in chunks of max_features
+    HIPC(f, hipMemcpyAsync(f->zmeas, uv, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    const float depth = f->cfg.default_point_depth;
+    const float inv_depth = (float)(1.0 / (double)depth);  // Feature.cpp:18  mu(2) = 1.0/depth
+    hipLaunchKernelGGL(add_features_kernel, dim3(64), dim3(256), 0, f->stream, f->P, f->ldp, f->n, count,
+                       f->cfg.default_point_homogenous_variance, f->cfg.default_point_depth_variance, f->mu,
+                       f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth);
+    HIPC(f, hipStreamSynchronize(f->stream));
+    f->N += count;
+    f->n += 3 * count;
+    return EKFVIO_OK;
+}
+
+int ekfvio_process(ekfvio_filter* f, float dt) {
+    if (!f || !(dt >= 0.f)) return EKFVIO_EINVAL;  // ROS_ASSERT(dt >= 0) EKFVIO.cpp:162
+    HIPC(f, hipSetDevice(f->device));
+    launch_predict(f, dt);
+    HIPC(f, hipGetLastError());
+    return EKFVIO_OK;
+}
+
+int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense) {
+    if (!f || !F_dense) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    launch_linearize(f, dt);
+    launch_build_dense_F(f, f->Fdense);
+    HIPC(f, hipMemcpy2DAsync(F_dense, sizeof(float) * f->n, f->Fdense, sizeof(float) * f->ldp, sizeof(float) * f->n,
+                             f->n, hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+static int finish_update(ekfvio_filter* f) {
+    HIPC(f, hipMemcpyAsync(f->h_info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    int bad = f->h_info[0];
+    if (bad) HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
+    return bad ? EKFVIO_ENUMERIC : EKFVIO_OK;
+}
+
+int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count) {
+    if (!f || count != f->N) return EKFVIO_EINVAL;  // ROS_ASSERT :478
+    if (count > 0 && (!z || !R || !pass)) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const int m = count_rows(pass, count);
+    if (count > 0) {
+        HIPC(f, hipMemcpyAsync(f->zmeas, z, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
+        HIPC(f, hipMemcpyAsync(f->Rmeas, R, sizeof(float) * 4 * count, hipMemcpyHostToDevice, f->stream));
+        HIPC(f, hipMemcpyAsync(f->pass, pass, count, hipMemcpyHostToDevice, f->stream));
+    }
+    launch_update(f, m, f->zmeas, f->Rmeas, f->pass);
+    HIPC(f, hipGetLastError());
+    return finish_update(f);
+}
+
+int ekfvio_measurement_map(const ekfvio_filter* f, const uint8_t* measured, int32_t count, int32_t* idx, int32_t* rows) {
+    if (!f || !measured || !idx || !rows || count != f->N) return EKFVIO_EINVAL;  // ROS_ASSERT :636
+    int r = 0;
+    for (int i = 0; i < count; i++)
+        if (measured[i]) {
+            idx[r++] = EKF_BASE + 3 * i;
+            idx[r++] = EKF_BASE + 3 * i + 1;
+        }
+    *rows = r;
+    return EKFVIO_OK;
+}
+
+int ekfvio_num_features(const ekfvio_filter* f) { return f ? f->N : -1; }
+int ekfvio_dim(const ekfvio_filter* f) { return f ? f->n : -1; }
+
+int ekfvio_get_base_mu(ekfvio_filter* f, float* base_mu) {
+    if (!f || !base_mu) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    HIPC(f, hipMemcpyAsync(base_mu, f->mu, sizeof(float) * EKF_BASE, hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_get_features(ekfvio_filter* f, float* mu3N, float* last_klt2N, uint8_t* delN) {
+    if (!f) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    if (f->N > 0) {
+        if (mu3N) HIPC(f, hipMemcpyAsync(mu3N, f->mu + EKF_BASE, sizeof(float) * 3 * f->N, hipMemcpyDeviceToHost, f->stream));
+        if (last_klt2N) HIPC(f, hipMemcpyAsync(last_klt2N, f->last_klt, sizeof(float) * 2 * f->N, hipMemcpyDeviceToHost, f->stream));
+        if (delN) HIPC(f, hipMemcpyAsync(delN, f->del_flag, f->N, hipMemcpyDeviceToHost, f->stream));
+    }
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_get_sigma(ekfvio_filter* f, float* sigma, int32_t ld) {
+    if (!f || !sigma || ld < f->n) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    HIPC(f, hipMemcpy2DAsync(sigma, sizeof(float) * ld, f->P, sizeof(float) * f->ldp, sizeof(float) * f->n, f->n,
+                             hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_get_feature_cov(ekfvio_filter* f, int32_t index, float cov[4]) {
+    if (!f || !cov || index < 0 || index >= f->N) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const int s = EKF_BASE + 3 * index;  // Sigma.block(start,start,2,2), column-major out
+    HIPC(f, hipMemcpy2DAsync(cov, sizeof(float) * 2, f->P + (size_t)s * f->ldp + s, sizeof(float) * f->ldp,
+                             sizeof(float) * 2, 2, hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_get_depth_variance(ekfvio_filter* f, int32_t index, float* var) {
+    if (!f || !var || index < 0 || index >= f->N) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const int s = EKF_BASE + 3 * index + 2;
+    HIPC(f, hipMemcpyAsync(var, f->P + (size_t)s * f->ldp + s, sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym) {
+    if (!f || !min_diag || !max_asym) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    launch_check_sigma(f, f->yres);  // yres is free between updates
+    float out[2];
+    HIPC(f, hipMemcpyAsync(out, f->yres, 2 * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    *min_diag = out[0];
+    *max_asym = out[1];
+    return EKFVIO_OK;
+}
+
+int ekfvio_set_state(ekfvio_filter* f, int32_t N, const float* base_mu, const float* mu3N, const float* last_klt2N,
+                     const uint8_t* delN, const float* sigma, int32_t ld) {
+    if (!f || N < 0 || !base_mu || !sigma) return EKFVIO_EINVAL;
+    if (N > f->cfg.max_features) return EKFVIO_ECAPACITY;
+    const int n = EKF_BASE + 3 * N;
+    if (ld < n || (N > 0 && (!mu3N || !last_klt2N || !delN))) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    HIPC(f, hipMemsetAsync(f->P, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
+    HIPC(f, hipMemsetAsync(f->mu, 0, sizeof(float) * f->ldp, f->stream));
+    HIPC(f, hipMemcpyAsync(f->mu, base_mu, sizeof(float) * EKF_BASE, hipMemcpyHostToDevice, f->stream));
+    if (N > 0) {
+        HIPC(f, hipMemcpyAsync(f->mu + EKF_BASE, mu3N, sizeof(float) * 3 * N, hipMemcpyHostToDevice, f->stream));
+        HIPC(f, hipMemcpyAsync(f->last_klt, last_klt2N, sizeof(float) * 2 * N, hipMemcpyHostToDevice, f->stream));
+        HIPC(f, hipMemcpyAsync(f->del_flag, delN, N, hipMemcpyHostToDevice, f->stream));
+    }
+    HIPC(f, hipMemcpy2DAsync(f->P, sizeof(float) * f->ldp, sigma, sizeof(float) * ld, sizeof(float) * n, n,
+                             hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    f->N = N;
+    f->n = n;
+    return EKFVIO_OK;
+}
+
+int ekfvio_imu(ekfvio_filter* f, double, const float*, const float*) { return f ? EKFVIO_OK : EKFVIO_EINVAL; }
+
+// ---- uploaded measurement sequences ---------------------------------------------------
+int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z, const float* R, const uint8_t* pass) {
+    if (!f || frames <= 0 || !z || !R || !pass || f->N <= 0) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    if (f->seq_z) hipFree(f->seq_z);
+    if (f->seq_R) hipFree(f->seq_R);
+    if (f->seq_pass) hipFree(f->seq_pass);
+    f->seq_z = f->seq_R = nullptr;
+    f->seq_pass = nullptr;
+    const size_t N = f->N;
+    HIPC(f, dev_alloc(&f->seq_z, frames * 2 * N));
+    HIPC(f, dev_alloc(&f->seq_R, frames * 4 * N));
+    HIPC(f, dev_alloc(&f->seq_pass, frames * N));
+    HIPC(f, hipMemcpy(f->seq_z, z, sizeof(float) * frames * 2 * N, hipMemcpyHostToDevice));
+    HIPC(f, hipMemcpy(f->seq_R, R, sizeof(float) * frames * 4 * N, hipMemcpyHostToDevice));
+    HIPC(f, hipMemcpy(f->seq_pass, pass, frames * N, hipMemcpyHostToDevice));
+    f->seq_frames = frames;
+    f->seq_N = (int)N;
+    f->seq_m.resize(frames);
+    for (int i = 0; i < frames; i++) f->seq_m[i] = count_rows(pass + (size_t)i * N, (int)N);
+    return EKFVIO_OK;
+}
+
+int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt) {
+    if (!f || f->seq_frames <= 0 || f->seq_N != f->N || count < 0 || first < 0 || !(dt >= 0.f)) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const size_t N = f->N;
+    for (int s = 0; s < count; s++) {
+        const int i = (first + s) % f->seq_frames;
+        launch_predict(f, dt);
+        launch_update(f, f->seq_m[i], f->seq_z + i * 2 * N, f->seq_R + i * 4 * N, f->seq_pass + i * N);
+    }
+    HIPC(f, hipGetLastError());
+    return EKFVIO_OK;
+}
+
+int ekfvio_synchronize(ekfvio_filter* f) {
+    if (!f) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+// ---- instrumentation ------------------------------------------------------------------
+int ekfvio_profile_enable(ekfvio_filter* f, int32_t on) {
+    if (!f) return EKFVIO_EINVAL;
+    hipStreamSynchronize(f->stream);
+    f->prof_on = on != 0;
+    return EKFVIO_OK;
+}
+int ekfvio_profile_reset(ekfvio_filter* f) {
+    if (!f) return EKFVIO_EINVAL;
+    for (int i = 0; i < PC_COUNT; i++) f->prof[i] = ProfSlot();
+    return EKFVIO_OK;
+}
+int ekfvio_profile_count(void) { return PC_COUNT; }
+const char* ekfvio_profile_name(int32_t cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t* launches, double* flops) {
+    if (!f || cls < 0 || cls >= PC_COUNT) return EKFVIO_EINVAL;
+    if (total_ms) *total_ms = f->prof[cls].ms;
+    if (launches) *launches = f->prof[cls].launches;
+    if (flops) *flops = f->prof[cls].flops;
+    return EKFVIO_OK;
+}
+
+// ---- raw kernels for unit tests -------------------------------------------------------
+int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
+                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc) {
+    if (!f || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    // device copies padded to the kernel's contract (64-row/col slack, K to 16, zero fill)
+    const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 16);
+    const int brows = transB ? Np : Kp, bcols = transB ? Kp : Np;
+    float *dA, *dB, *dC;
+    HIPC(f, dev_alloc(&dA, (size_t)Mp * Kp));
+    HIPC(f, dev_alloc(&dB, (size_t)brows * bcols));
+    HIPC(f, dev_alloc(&dC, (size_t)Mp * Np));
+    HIPC(f, hipMemcpy2D(dA, sizeof(float) * Mp, A, sizeof(float) * lda, sizeof(float) * M, K, hipMemcpyHostToDevice));
+    HIPC(f, hipMemcpy2D(dB, sizeof(float) * brows, B, sizeof(float) * ldb, sizeof(float) * (transB ? N : K),
+                        transB ? K : N, hipMemcpyHostToDevice));
+    HIPC(f, hipMemcpy2D(dC, sizeof(float) * Mp, C, sizeof(float) * ldc, sizeof(float) * M, N, hipMemcpyHostToDevice));
+    launch_gemm(f->stream, transB, M, N, Kp, alpha, dA, Mp, dB, brows, beta, dC, Mp, dC, Mp, 0);
+    HIPC(f, hipStreamSynchronize(f->stream));
+    HIPC(f, hipMemcpy2D(C, sizeof(float) * ldc, dC, sizeof(float) * Mp, sizeof(float) * M, N, hipMemcpyDeviceToHost));
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dC);
+    return EKFVIO_OK;
+}
+
+int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
+                               float* L_out, float* X_out, int32_t* info) {
+    // S: m x m (ld m) SPD; Crhs: nrhs x m (ld nrhs); L_out m x m; X_out = Crhs * S^-1 (nrhs x m)
+    if (!f || m <= 0 || nrhs <= 0 || !S || !Crhs) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const int mp = round_up(m, 64), rp = round_up(nrhs, 64);
+    float *dS, *dL, *dLi, *dX, *dW;
+    HIPC(f, dev_alloc(&dS, (size_t)mp * mp));
+    HIPC(f, dev_alloc(&dL, (size_t)mp * mp));
+    HIPC(f, dev_alloc(&dLi, (size_t)64 * mp));
+    HIPC(f, dev_alloc(&dX, (size_t)rp * mp));
+    HIPC(f, dev_alloc(&dW, (size_t)rp * mp));
+    std::vector<float> hs((size_t)mp * mp, 0.f);
+    for (int c = 0; c < mp; c++)
+        for (int r = 0; r < mp; r++) hs[(size_t)c * mp + r] = (r < m && c < m) ? S[(size_t)c * m + r] : (r == c ? 1.f : 0.f);
+    HIPC(f, hipMemcpy(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice));
+    HIPC(f, hipMemcpy2D(dX, sizeof(float) * rp, Crhs, sizeof(float) * nrhs, sizeof(float) * nrhs, m, hipMemcpyHostToDevice));
+    launch_cholesky(f, dS, dL, dLi, mp, mp);
+    launch_solve_right(f, dL, dLi, mp, mp, dX, dW, nrhs, rp);
+    HIPC(f, hipStreamSynchronize(f->stream));
+    if (L_out) HIPC(f, hipMemcpy2D(L_out, sizeof(float) * m, dL, sizeof(float) * mp, sizeof(float) * m, m, hipMemcpyDeviceToHost));
+    if (X_out) HIPC(f, hipMemcpy2D(X_out, sizeof(float) * nrhs, dX, sizeof(float) * rp, sizeof(float) * nrhs, m, hipMemcpyDeviceToHost));
+    if (info) {
+        HIPC(f, hipMemcpy(info, f->info, sizeof(int), hipMemcpyDeviceToHost));
+        HIPC(f, hipMemset(f->info, 0, sizeof(int)));
+    }
+    hipFree(dS);
+    hipFree(dL);
+    hipFree(dLi);
+    hipFree(dX);
+    hipFree(dW);
+    return EKFVIO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// ekf_vio_amd/csrc/common.h — internal declarations shared by the HIP translation units.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, fp32 MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ekfvio.h"
+
+#define EKF_BASE 22
+#define EKF_TILE 64  // block size of every blocked algorithm (GEMM tile edge, Cholesky nb)
+// prune(SPARSE_THRESH, SPARSE_EPS) keeps |x| > 1e-8f*1e-5f (TightlyCoupledEKF.h:13-14, .cpp:117,580,591,625)
+#define EKF_FLUSH_THRESH (1e-8f * 1e-5f)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Kernel classes for the built-in event profiler (ekfvio_profile_*).
+enum ProfClass {
+    PC_LINEARIZE = 0,
+    PC_PREDICT,
+    PC_GEMM_PREDICT,
+    PC_GATHER,
+    PC_CHOL,
+    PC_SOLVE,
+    PC_GEMM_UPDATE,
+    PC_UPDATE_MISC,
+    PC_KLT_PYRAMID,
+    PC_KLT_TRACK,
+    PC_COUNT
+};
+
+struct ProfSlot {
+    double ms = 0;
+    int64_t launches = 0;
+    double flops = 0;
+};
+
+struct KltFrame {
+    // Pyramid level l: 8-bit image with a border of `border` pixels on every side
+    // (reflect-101), and interleaved int16 (dx,dy) Scharr derivatives with a zero border.
+    uint8_t* img[8] = {nullptr};
+    short* deriv[8] = {nullptr};
+    int w[8] = {0}, h[8] = {0};
+    int levels = 0;  // number of valid levels (maxLevel+1)
+    float K[9] = {0};
+    bool valid = false;
+};
+
+struct ekfvio_filter {
+    ekfvio_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+
+    int N = 0;      // landmarks
+    int n = EKF_BASE;
+    int n_cap = 0;  // 22 + 3*max_features
+    int ldp = 0;    // leading dimension of every n-row matrix (multiple of 64)
+    int m_cap = 0;  // 2*max_features rounded up to 64; leading dimension of S/L
+
+    // --- state (device) ---
+    float* mu = nullptr;       // [ldp]  base (22) then [u,v,1/d] per landmark
+    float* mu_next = nullptr;  // [ldp]  scratch for the propagated mean
+    float* last_klt = nullptr; // [2*max_features]
+    uint8_t* del_flag = nullptr;  // [max_features]
+    float* P = nullptr;        // [ldp*ldp] dense covariance, column-major
+    float* P2 = nullptr;       // [ldp*ldp] ping-pong / scratch (X = F P, dense F)
+    // --- process Jacobian blocks ---
+    float* FA = nullptr;       // [22*22] column-major
+    float* FB = nullptr;       // [max_features*27]  per landmark [9 cols (state 7..15)][3 rows]
+    float* FD = nullptr;       // [max_features*9]   per landmark [3 cols][3 rows]
+    float* Fdense = nullptr;   // [ldp*ldp] only in dense predict mode / ekfvio_linearize
+    // --- update work ---
+    int* idx = nullptr;        // [m_cap] state index of measurement row r
+    float* zmeas = nullptr;    // [2*max_features] device copy of z
+    float* Rmeas = nullptr;    // [4*max_features]
+    uint8_t* pass = nullptr;   // [max_features]
+    float* yres = nullptr;     // [m_cap] residual
+    float* Rm = nullptr;       // [m_cap*2] per measurement row r: R(r,r) and the off-diagonal partner
+    float* S = nullptr;        // [m_cap*m_cap]
+    float* L = nullptr;        // [m_cap*m_cap] Cholesky factor (lower)
+    float* Linv = nullptr;     // [64*m_cap] inverses of the diagonal blocks of L
+    float* Km = nullptr;       // [ldp*m_cap]  Sigma H^T, solved in place into the Kalman gain
+    float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
+    float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
+    int* info = nullptr;       // [4] device flags: [0] non-positive pivot seen
+    int* h_info = nullptr;     // pinned host mirror
+    // uploaded measurement sequences
+    float* seq_z = nullptr;
+    float* seq_R = nullptr;
+    uint8_t* seq_pass = nullptr;
+    int seq_frames = 0;
+    int seq_N = 0;
+    std::vector<int> seq_m;                 // measurement rows per uploaded frame
+    std::vector<std::vector<uint8_t>> seq_pass_host;
+
+    // --- KLT ---
+    KltFrame frames[2];
+    int cur = 0;          // index of the current frame in frames[]
+    int klt_border = 0;
+    float* klt_prev_px = nullptr;  // [2*max_features]
+    float* klt_next_px = nullptr;  // [2*max_features]
+    uint8_t* klt_status = nullptr; // [max_features]
+    uint8_t* staging = nullptr;    // device staging for the uploaded image
+    double t_stamp = 0;
+    bool have_stamp = false;
+
+    // --- profiler ---
+    bool prof_on = false;
+    ProfSlot prof[PC_COUNT];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// ---- launchers implemented across the translation units -------------------------------
+// C[MxN] = beta*Cin + alpha * A[MxK] * op(B); all column-major.  transB: B is [NxK]
+// (op = transpose) else [KxN].  K must be a multiple of 16 and the K-padding of both
+// operands finite*0-safe (zero).  flush != 0 applies the reference's prune (|x|<=1e-13 -> 0).
+void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush);
+
+void launch_linearize(ekfvio_filter* f, float dt);
+void launch_build_dense_F(ekfvio_filter* f, float* Fdense);
+void launch_predict(ekfvio_filter* f, float dt);
+void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass);
+void launch_check_sigma(ekfvio_filter* f, float* d_out);
+// Cholesky of S (m_pad x m_pad, ld = lds; lower) into L, diagonal-block inverses into Linv,
+// then X <- X * S^-1 for the nrows x m_pad matrix X (ld = ldx) in place; W is scratch of the same shape.
+void launch_cholesky(ekfvio_filter* f, float* S, float* L, float* Linv, int m_pad, int lds);
+void launch_solve_right(ekfvio_filter* f, const float* L, const float* Linv, int m_pad, int lds, float* X, float* W,
+                        int nrows, int ldx);
+
+int klt_alloc(ekfvio_filter* f);  // klt.hip
+void klt_free(ekfvio_filter* f);
+
+struct ProfScope {
+    ekfvio_filter* f;
+    int cls;
+    ProfScope(ekfvio_filter* f_, int cls_, double flops = 0) : f(f_), cls(cls_) {
+        if (f->prof_on) {
+            (void)hipEventRecord(f->ev0, f->stream);
+            f->prof[cls].flops += flops;
+        }
+    }
+    ~ProfScope() {
+        if (f->prof_on) {
+            (void)hipEventRecord(f->ev1, f->stream);
+            (void)hipEventSynchronize(f->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, f->ev0, f->ev1);
+            f->prof[cls].ms += ms;
+            f->prof[cls].launches += 1;
+        }
+    }
+};

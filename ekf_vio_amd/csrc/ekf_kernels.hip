@@ -1,0 +1,574 @@
+// ekf_vio_amd/csrc/ekf_kernels.hip — process model, finite-difference linearisation,
+// structured covariance propagation and the gather/scatter kernels of the update.
+//
+// Reference: include/ekf_vio/TightlyCoupledEKF.cpp — process :96-121, Q :123-174, FD
+// Jacobian :176-325, convolveBaseState :328-395, convolveFeature :397-460, update
+// bookkeeping :486-541, residual :554-555, mean update :600-620.
+//
+// This translation unit is compiled with -ffp-contract=off and evaluates every expression
+// in the reference's operation order (including the places where a double literal makes the
+// reference compute in double), so the Jacobian blocks and propagated means agree with an
+// x86-64 build of the same formulas to the last bit wherever the math library does.
+#include "common.h"
+
+namespace {
+
+struct Q4 {
+    float w, x, y, z;
+};
+struct V3 {
+    float x, y, z;
+};
+
+__device__ inline V3 cross3(const V3& a, const V3& b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Eigen QuaternionBase::_transformVector: v + w*uv + qv x uv, uv = 2 (qv x v)
+__device__ inline V3 qrot(const Q4& q, const V3& v) {
+    V3 qv{q.x, q.y, q.z};
+    V3 uv = cross3(qv, v);
+    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+    V3 c = cross3(qv, uv);
+    return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+__device__ inline Q4 qinverse(const Q4& q) {
+    float n2 = (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+    if (n2 > 0.f) return {q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
+    return {0.f, 0.f, 0.f, 0.f};
+}
+__device__ inline Q4 qnormalized(const Q4& q) {
+    float n = sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+    return {q.w / n, q.x / n, q.y / n, q.z / n};
+}
+__device__ inline Q4 qmul(const Q4& a, const Q4& b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ inline float norm3(const V3& v) { return sqrtf(v.x * v.x + (v.y * v.y + v.z * v.z)); }
+
+// dt*vel + 0.5*dt*dt*accel with the 0.5*dt*dt factor evaluated in double (:338, :420)
+__device__ inline V3 translation(const V3& vel, const V3& acc, float dt) {
+    float h = (float)(0.5 * (double)dt * (double)dt);
+    return {dt * vel.x + h * acc.x, dt * vel.y + h * acc.y, dt * vel.z + h * acc.z};
+}
+// exp(omega dt) (:340-355); sign = -1 is the conjugate built by convolveFeature (:427-440)
+__device__ inline Q4 delta_quat(const V3& om, float dt, float sign) {
+    float on = norm3(om);
+    if (on < 1e-10f) {
+        Q4 q{1.f, sign * om.x * dt, sign * om.y * dt, sign * om.z * dt};
+        return qnormalized(q);
+    }
+    float theta = dt * on;
+    V3 oh{om.x / on, om.y / on, om.z / on};
+    float half = theta / 2;
+    float st2 = (float)sin((double)half);
+    float ct2 = (float)cos((double)half);
+    return {ct2, sign * oh.x * st2, sign * oh.y * st2, sign * oh.z * st2};
+}
+
+// convolveBaseState (:328-395)
+__device__ inline void convolve_base(const float* last, float dt, float* out) {
+    V3 pos{last[0], last[1], last[2]};
+    Q4 quat{last[3], last[4], last[5], last[6]};
+    V3 vel{last[7], last[8], last[9]};
+    V3 om{last[10], last[11], last[12]};
+    V3 acc{last[13], last[14], last[15]};
+    V3 d = qrot(quat, translation(vel, acc, dt));
+    pos = {pos.x + d.x, pos.y + d.y, pos.z + d.z};
+    Q4 dq = delta_quat(om, dt, 1.f);
+    Q4 dqi = qinverse(dq);
+    V3 va{vel.x + dt * acc.x, vel.y + dt * acc.y, vel.z + dt * acc.z};
+    vel = qrot(dqi, va);
+    acc = qrot(dqi, acc);
+    quat = qmul(quat, dq);
+    out[0] = pos.x; out[1] = pos.y; out[2] = pos.z;
+    out[3] = quat.w; out[4] = quat.x; out[5] = quat.y; out[6] = quat.z;
+    out[7] = vel.x; out[8] = vel.y; out[9] = vel.z;
+    out[10] = last[10]; out[11] = last[11]; out[12] = last[12];
+    out[13] = acc.x; out[14] = acc.y; out[15] = acc.z;
+    for (int i = 16; i < EKF_BASE; i++) out[i] = last[i];
+}
+
+// The part of convolveFeature that depends on the base state only (:405-446): the inverse
+// frame rotation and the rotated translation are shared by all landmarks.
+struct BaseMotion {
+    Q4 dqi;
+    V3 rt;  // dq_inv * translation
+};
+__device__ inline BaseMotion base_motion(const float* base, float dt) {
+    V3 vel{base[7], base[8], base[9]};
+    V3 acc{base[13], base[14], base[15]};
+    V3 om{base[10], base[11], base[12]};
+    BaseMotion bm;
+    bm.dqi = delta_quat(om, dt, -1.f);
+    bm.rt = qrot(bm.dqi, translation(vel, acc, dt));
+    return bm;
+}
+// convolveFeature (:397-460) given the base-dependent part
+__device__ inline V3 convolve_feature(const BaseMotion& bm, float u, float v, float rho) {
+    V3 p;
+    p.z = (float)(1.0 / (double)rho);
+    p.x = u * p.z;
+    p.y = v * p.z;
+    V3 a = qrot(bm.dqi, p);
+    p = {a.x + (-bm.rt.x), a.y + (-bm.rt.y), a.z + (-bm.rt.z)};
+    p.x /= p.z;
+    p.y /= p.z;
+    p.z = (float)(1.0 / (double)p.z);
+    return p;
+}
+
+__device__ inline float plus_delta(float x) { return (float)((double)x + 1e-3); }
+__device__ inline float minus_2delta(float x) { return (float)((double)x - 2 * 1e-3); }
+__device__ inline float two_delta() { return (float)(2 * 1e-3); }
+
+// ---------------------------------------------------------------------------------------
+// numericallyLinearizeProcess + mean propagation in one launch.
+// Block 0 additionally produces the 22x22 base block A and the propagated base mean.
+// Every block first evaluates the 19 base-state variants (unperturbed + 9 columns x {+,-})
+// that the landmark rows need, into LDS; then one lane per landmark evaluates its 24
+// perturbed motions plus the propagated mean and writes its 3x9 and 3x3 Jacobian blocks.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void linearize_kernel(const float* __restrict__ mu, int N, float dt, float* FA,
+                                                       float* FB, float* FD, float* mu_next) {
+    __shared__ float s_base[EKF_BASE];
+    __shared__ BaseMotion s_bm[19];            // 0: unperturbed, 1+2c: col 7+c plus, 2+2c: minus
+    __shared__ float s_hi[16][EKF_BASE];       // block 0: convolveBaseState at +delta
+    __shared__ float s_lo[16][EKF_BASE];
+    const int tid = threadIdx.x;
+    if (tid < EKF_BASE) s_base[tid] = mu[tid];
+    __syncthreads();
+    if (tid < 19) {
+        float t[EKF_BASE];
+        for (int i = 0; i < EKF_BASE; i++) t[i] = s_base[i];
+        if (tid > 0) {
+            int c = 7 + (tid - 1) / 2;
+            t[c] = plus_delta(t[c]);
+            if (((tid - 1) & 1) == 1) t[c] = minus_2delta(t[c]);
+        }
+        s_bm[tid] = base_motion(t, dt);
+    }
+    if (blockIdx.x == 0 && tid >= 32 && tid < 64) {
+        // 32 evaluations of convolveBaseState: column j = 0..15, high and low test points
+        int e = tid - 32;
+        int j = e >> 1;
+        float t[EKF_BASE], o[EKF_BASE];
+        for (int i = 0; i < EKF_BASE; i++) t[i] = s_base[i];
+        t[j] = plus_delta(t[j]);
+        if (e & 1) t[j] = minus_2delta(t[j]);
+        convolve_base(t, dt, o);
+        for (int i = 0; i < EKF_BASE; i++) (e & 1 ? s_lo : s_hi)[j][i] = o[i];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        const float td = two_delta();
+        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 64) {
+            int j = e / EKF_BASE, i = e % EKF_BASE;
+            float v;
+            if (j < 16)
+                v = (s_hi[j][i] - s_lo[j][i]) / td;
+            else
+                v = (i == j) ? 1.f : 0.f;
+            FA[e] = v;
+        }
+        if (tid == 0) {
+            float o[EKF_BASE];
+            convolve_base(s_base, dt, o);
+            for (int i = 0; i < EKF_BASE; i++) mu_next[i] = o[i];
+        }
+    }
+    const int f = blockIdx.x * 64 + tid;
+    if (f >= N) return;
+    const float u = mu[EKF_BASE + 3 * f], v = mu[EKF_BASE + 3 * f + 1], rho = mu[EKF_BASE + 3 * f + 2];
+    const float td = two_delta();
+    // columns 7..15 of the landmark's rows (:223-253)
+    for (int c = 0; c < 9; c++) {
+        V3 hi = convolve_feature(s_bm[1 + 2 * c], u, v, rho);
+        V3 lo = convolve_feature(s_bm[2 + 2 * c], u, v, rho);
+        float* o = FB + (size_t)f * 27 + c * 3;
+        o[0] = (hi.x - lo.x) / td;
+        o[1] = (hi.y - lo.y) / td;
+        o[2] = (hi.z - lo.z) / td;
+    }
+    // the landmark's own 3x3 block (:262-321)
+    float base3[3] = {u, v, rho};
+    for (int c = 0; c < 3; c++) {
+        float t[3] = {u, v, rho};
+        t[c] = plus_delta(t[c]);
+        V3 hi = convolve_feature(s_bm[0], t[0], t[1], t[2]);
+        t[c] = minus_2delta(t[c]);
+        V3 lo = convolve_feature(s_bm[0], t[0], t[1], t[2]);
+        t[c] = base3[c];
+        float* o = FD + (size_t)f * 9 + c * 3;
+        o[0] = (hi.x - lo.x) / td;
+        o[1] = (hi.y - lo.y) / td;
+        o[2] = (hi.z - lo.z) / td;
+    }
+    // mean propagation with the OLD base state (:102-104)
+    V3 pm = convolve_feature(s_bm[0], u, v, rho);
+    mu_next[EKF_BASE + 3 * f] = pm.x;
+    mu_next[EKF_BASE + 3 * f + 1] = pm.y;
+    mu_next[EKF_BASE + 3 * f + 2] = pm.z;
+}
+
+// Scatter the Jacobian blocks into a dense n x n matrix (column-major, ld), zero elsewhere.
+__global__ void build_dense_F_kernel(const float* FA, const float* FB, const float* FD, int N, int n, int ld, float* F) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= ld || j >= ld) return;
+    float v = 0.f;
+    if (i < n && j < n) {
+        if (i < EKF_BASE) {
+            if (j < EKF_BASE) v = FA[j * EKF_BASE + i];
+        } else {
+            int f = (i - EKF_BASE) / 3, r = (i - EKF_BASE) % 3;
+            if (j >= 7 && j <= 15)
+                v = FB[(size_t)f * 27 + (j - 7) * 3 + r];
+            else if (j >= EKF_BASE && (j - EKF_BASE) / 3 == f)
+                v = FD[(size_t)f * 9 + ((j - EKF_BASE) % 3) * 3 + r];
+        }
+    }
+    F[(size_t)j * ld + i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Structured covariance propagation.  F = [[A 0],[B D]] with B non-zero only in state
+// columns 7..15 and D block-diagonal 3x3, so
+//   X = F*P      : row i<22 : sum_{k<22} A(i,k) P(k,j);  landmark row: 9 + 3 terms
+//   P'= X*F^T + Q: col j<22 : sum_{k<22} X(i,k) A(j,k);  landmark col: 9 + 3 terms
+// Terms are accumulated in ascending state index with separate multiply and add, i.e. the
+// order of the reference's sparse products (and of the dense oracle, whose extra terms are
+// exact zeros).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void predict_x_kernel(const float* __restrict__ P, int ld, int n,
+                                                        const float* __restrict__ FA, const float* __restrict__ FB,
+                                                        const float* __restrict__ FD, float* __restrict__ X) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= n) return;
+    const float* pc = P + (size_t)j * ld;
+    float acc = 0.f;
+    if (i < EKF_BASE) {
+        for (int k = 0; k < EKF_BASE; k++) acc = acc + FA[k * EKF_BASE + i] * pc[k];
+    } else {
+        const int f = (i - EKF_BASE) / 3, r = (i - EKF_BASE) % 3;
+        const float* b = FB + (size_t)f * 27 + r;
+        for (int c = 0; c < 9; c++) acc = acc + b[c * 3] * pc[7 + c];
+        const float* d = FD + (size_t)f * 9 + r;
+        const int k0 = EKF_BASE + 3 * f;
+        for (int q = 0; q < 3; q++) acc = acc + d[q * 3] * pc[k0 + q];
+    }
+    X[(size_t)j * ld + i] = acc;
+}
+
+__device__ inline float process_noise(int i, float dt) {
+    // generateProcessNoise (:123-174)
+    if (i < 7) return (float)(0.0001 * (double)dt);
+    if (i < 10) return (float)(0.01 * (double)dt);
+    if (i < 16) return 5 * dt;
+    if (i < 22) return (float)(0.001 * (double)dt);
+    return (float)(0.0001 * (double)dt);
+}
+
+__global__ __launch_bounds__(256) void predict_p_kernel(const float* __restrict__ X, int ld, int n,
+                                                        const float* __restrict__ FA, const float* __restrict__ FB,
+                                                        const float* __restrict__ FD, float dt, float* __restrict__ Pout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= n) return;
+    float acc = 0.f;
+    if (j < EKF_BASE) {
+        for (int k = 0; k < EKF_BASE; k++) acc = acc + X[(size_t)k * ld + i] * FA[k * EKF_BASE + j];
+    } else {
+        const int g = (j - EKF_BASE) / 3, s = (j - EKF_BASE) % 3;
+        const float* b = FB + (size_t)g * 27 + s;
+        for (int c = 0; c < 9; c++) acc = acc + X[(size_t)(7 + c) * ld + i] * b[c * 3];
+        const float* d = FD + (size_t)g * 9 + s;
+        const int k0 = EKF_BASE + 3 * g;
+        for (int q = 0; q < 3; q++) acc = acc + X[(size_t)(k0 + q) * ld + i] * d[q * 3];
+    }
+    if (i == j) acc = acc + process_noise(i, dt);
+    if (!(fabsf(acc) > EKF_FLUSH_THRESH)) acc = 0.f;
+    Pout[(size_t)j * ld + i] = acc;
+}
+
+// dense mode epilogue: P += Q(dt) on the diagonal, then prune
+__global__ void add_noise_flush_kernel(float* P, int ld, int n, float dt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= n) return;
+    float v = P[(size_t)j * ld + i];
+    if (i == j) v = v + process_noise(i, dt);
+    if (!(fabsf(v) > EKF_FLUSH_THRESH)) v = 0.f;
+    P[(size_t)j * ld + i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Update bookkeeping (:486-541, :554-555): one workgroup scans the pass flags into the
+// measurement map idx (formFeatureMeasurementMap :634-661), stores last_klt / delete flags,
+// z - H*mu and the per-row measurement noise.  Integer work is bit-exact by construction.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_pad, const float* __restrict__ z,
+                                                                  const float* __restrict__ R,
+                                                                  const uint8_t* __restrict__ pass,
+                                                                  const float* __restrict__ mu, float* last_klt,
+                                                                  uint8_t* del_flag, int* idx, float* yres, float* Rm) {
+    __shared__ int s_cnt[1024];
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    const int lo = tid * per;
+    const int hi = min(N, lo + per);
+    int c = 0;
+    for (int i = lo; i < hi; i++) c += pass[i] ? 1 : 0;
+    s_cnt[tid] = c;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partial counts
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? s_cnt[tid - off] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int base = s_cnt[tid] - c;
+    if (tid == 1023) s_total = s_cnt[1023];
+    for (int i = lo; i < hi; i++) {
+        if (pass[i]) {
+            const int r = 2 * base;
+            const int s = EKF_BASE + 3 * i;
+            last_klt[2 * i] = z[2 * i];
+            last_klt[2 * i + 1] = z[2 * i + 1];
+            idx[r] = s;
+            idx[r + 1] = s + 1;
+            yres[r] = z[2 * i] - mu[s];
+            yres[r + 1] = z[2 * i + 1] - mu[s + 1];
+            // Rm[2c] = R(c,c), Rm[2c+1] = R(c^1,c) (the off-diagonal element of column c);
+            // input is a column-major 2x2: [cov(0,0), cov(1,0), cov(0,1), cov(1,1)]
+            Rm[2 * r] = R[4 * i + 0];
+            Rm[2 * r + 1] = R[4 * i + 1];
+            Rm[2 * r + 2] = R[4 * i + 3];
+            Rm[2 * r + 3] = R[4 * i + 2];
+            base++;
+        } else {
+            del_flag[i] = 1;
+        }
+    }
+    __syncthreads();
+    const int m = 2 * s_total;
+    for (int r = m + tid; r < m_pad; r += 1024) {
+        idx[r] = -1;
+        yres[r] = 0.f;
+        Rm[2 * r] = 0.f;
+        Rm[2 * r + 1] = 0.f;
+    }
+}
+
+// S = H Sigma H^T + R (:559-561), padded with the identity; C = Sigma H^T (columns of
+// Sigma); Wt = (H Sigma)^T (rows of Sigma, transposed so that it is state-major).
+__global__ __launch_bounds__(256) void gather_S_kernel(const float* __restrict__ P, int ld, const int* __restrict__ idx,
+                                                       const float* __restrict__ Rm, int m, int m_pad, float* S,
+                                                       int lds) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= m_pad) return;
+    float v;
+    if (r < m && c < m) {
+        v = P[(size_t)idx[c] * ld + idx[r]];
+        if (r == c)
+            v = v + Rm[2 * r];
+        else if ((r ^ 1) == c)
+            v = v + Rm[2 * c + 1];  // off-diagonal element of column c
+    } else {
+        v = (r == c) ? 1.f : 0.f;
+    }
+    S[(size_t)c * lds + r] = v;
+}
+
+__global__ __launch_bounds__(256) void gather_CW_kernel(const float* __restrict__ P, int ld, int n,
+                                                        const int* __restrict__ idx, int m, int m_pad, float* C,
+                                                        float* Wt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i >= ld) return;
+    float c = 0.f, w = 0.f;
+    if (r < m && i < n) {
+        const int s = idx[r];
+        c = P[(size_t)s * ld + i];   // Sigma(i, idx[r])
+        w = P[(size_t)i * ld + s];   // Sigma(idx[r], i)
+    }
+    C[(size_t)r * ld + i] = c;
+    Wt[(size_t)r * ld + i] = w;
+}
+
+// K <- prune(K) (sparseView :580) on the logical n x m block
+__global__ void flush_kernel(float* K, int ld, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i >= n) return;
+    float v = K[(size_t)r * ld + i];
+    if (!(fabsf(v) > EKF_FLUSH_THRESH)) K[(size_t)r * ld + i] = 0.f;
+}
+
+// G = K*R - T[:, idx]   (so that Sigma' = T + G*K^T = T*I_KH^T + K*R*K^T, :594-596)
+__global__ __launch_bounds__(256) void form_G_kernel(const float* __restrict__ K, const float* __restrict__ T, int ld,
+                                                     int n, const int* __restrict__ idx, const float* __restrict__ Rm,
+                                                     int m, float* G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i >= ld) return;
+    float g = 0.f;
+    if (r < m && i < n) {
+        const int p = r ^ 1;  // partner row of the same landmark
+        // (K R)(i,r) = K(i,r) R(r,r) + K(i,p) R(p,r); ascending measurement index like the reference
+        const float rrr = Rm[2 * r];
+        const float rpr = Rm[2 * r + 1];  // R(p,r): the off-diagonal element of column r
+        float kr;
+        if (p < r)
+            kr = K[(size_t)p * ld + i] * rpr + K[(size_t)r * ld + i] * rrr;
+        else
+            kr = K[(size_t)r * ld + i] * rrr + K[(size_t)p * ld + i] * rpr;
+        g = kr - T[(size_t)idx[r] * ld + i];
+    }
+    G[(size_t)r * ld + i] = g;
+}
+
+// mu += K*y (:600), quaternion renormalisation (:605-609).  One thread per state row.
+__global__ __launch_bounds__(256) void mean_update_kernel(const float* __restrict__ K, int ld, int n, int m,
+                                                          const float* __restrict__ y, float* mu) {
+    __shared__ float s_q[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+        float acc = 0.f;
+        for (int r = 0; r < m; r++) acc = acc + K[(size_t)r * ld + i] * y[r];
+        v = mu[i] + acc;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x >= 3 && threadIdx.x <= 6) s_q[threadIdx.x - 3] = v;
+        __syncthreads();
+        if (threadIdx.x >= 3 && threadIdx.x <= 6) {
+            float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
+            v = v / qn;
+        }
+    }
+    if (i < n) mu[i] = v;
+}
+
+__global__ void check_sigma_kernel(const float* P, int ld, int n, float* out) {
+    // out[0] = min diagonal, out[1] = max |P(i,j)-P(j,i)|; single block
+    __shared__ float s_min[256], s_max[256];
+    float mn = 3.4e38f, mx = 0.f;
+    for (size_t e = threadIdx.x; e < (size_t)n * n; e += 256) {
+        int i = e % n, j = e / n;
+        if (i == j) mn = fminf(mn, P[(size_t)j * ld + i]);
+        if (i > j) mx = fmaxf(mx, fabsf(P[(size_t)j * ld + i] - P[(size_t)i * ld + j]));
+    }
+    s_min[threadIdx.x] = mn;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            s_min[threadIdx.x] = fminf(s_min[threadIdx.x], s_min[threadIdx.x + s]);
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s_min[0];
+        out[1] = s_max[0];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+void launch_linearize(ekfvio_filter* f, float dt) {
+    ProfScope ps(f, PC_LINEARIZE);
+    int blocks = (f->N + 63) / 64;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(linearize_kernel, dim3(blocks), dim3(64), 0, f->stream, f->mu, f->N, dt, f->FA, f->FB, f->FD,
+                       f->mu_next);
+}
+
+void launch_build_dense_F(ekfvio_filter* f, float* Fdense) {
+    dim3 grid((f->ldp + 255) / 256, f->ldp);
+    hipLaunchKernelGGL(build_dense_F_kernel, grid, dim3(256), 0, f->stream, f->FA, f->FB, f->FD, f->N, f->n, f->ldp,
+                       Fdense);
+}
+
+// process(dt) (:96-121)
+void launch_predict(ekfvio_filter* f, float dt) {
+    launch_linearize(f, dt);
+    const int n = f->n, ld = f->ldp;
+    dim3 grid((n + 255) / 256, n);
+    if (f->cfg.predict_mode == EKFVIO_PREDICT_DENSE) {
+        launch_build_dense_F(f, f->Fdense);
+        const int np = round_up(n, 16);
+        {
+            ProfScope ps(f, PC_GEMM_PREDICT, 4.0 * n * (double)n * n);
+            // X = F*P (B = P is [K x N]); P' = X*F^T (B = F is [N x K])
+            launch_gemm(f->stream, 0, n, n, np, 1.f, f->Fdense, ld, f->P, ld, 0.f, nullptr, 0, f->P2, ld, 0);
+            launch_gemm(f->stream, 1, n, n, np, 1.f, f->P2, ld, f->Fdense, ld, 0.f, nullptr, 0, f->P, ld, 0);
+        }
+        ProfScope ps(f, PC_PREDICT);
+        hipLaunchKernelGGL(add_noise_flush_kernel, grid, dim3(256), 0, f->stream, f->P, ld, n, dt);
+    } else {
+        ProfScope ps(f, PC_PREDICT, 4.0 * n * (358.0 + 36.0 * f->N));
+        hipLaunchKernelGGL(predict_x_kernel, grid, dim3(256), 0, f->stream, f->P, ld, n, f->FA, f->FB, f->FD, f->P2);
+        hipLaunchKernelGGL(predict_p_kernel, grid, dim3(256), 0, f->stream, f->P2, ld, n, f->FA, f->FB, f->FD, dt,
+                           f->P);
+    }
+    // the propagated mean becomes the state (landmarks used the OLD base state, :102-107)
+    hipMemcpyAsync(f->mu, f->mu_next, sizeof(float) * f->n, hipMemcpyDeviceToDevice, f->stream);
+}
+
+// updateWithFeaturePositions (:475-628) on device-resident z/R/pass; m = 2*(#passed) known to the host
+void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass) {
+    const int n = f->n, ld = f->ldp, N = f->N;
+    const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
+    const int lds = f->m_cap;
+    {
+        ProfScope ps(f, PC_GATHER);
+        hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, N, m_pad, d_z, d_R, d_pass,
+                           f->mu, f->last_klt, f->del_flag, f->idx, f->yres, f->Rm);
+        if (m > 0) {
+            hipLaunchKernelGGL(gather_S_kernel, dim3((m_pad + 255) / 256, m_pad), dim3(256), 0, f->stream, f->P, ld,
+                               f->idx, f->Rm, m, m_pad, f->S, lds);
+            hipLaunchKernelGGL(gather_CW_kernel, dim3((ld + 255) / 256, m_pad), dim3(256), 0, f->stream, f->P, ld, n,
+                               f->idx, m, m_pad, f->Km, f->Wt);
+        }
+    }
+    if (m > 0) {
+        launch_cholesky(f, f->S, f->L, f->Linv, m_pad, lds);
+        // K = (Sigma H^T) S^-1  (:577-580), in place in Km; Gm is scratch until form_G
+        launch_solve_right(f, f->L, f->Linv, m_pad, lds, f->Km, f->Gm, n, ld);
+        {
+            ProfScope ps(f, PC_UPDATE_MISC);
+            hipLaunchKernelGGL(flush_kernel, dim3((n + 255) / 256, m), dim3(256), 0, f->stream, f->Km, ld, n);
+        }
+        {
+            // T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place
+            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);
+            launch_gemm(f->stream, 1, n, n, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0);
+        }
+        {
+            ProfScope ps(f, PC_UPDATE_MISC);
+            hipLaunchKernelGGL(form_G_kernel, dim3((ld + 255) / 256, m_pad), dim3(256), 0, f->stream, f->Km, f->P, ld, n,
+                               f->idx, f->Rm, m, f->Gm);
+        }
+        {
+            // Sigma' = T + G*K^T, pruned (:594-596, :625)
+            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);
+            launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1);
+        }
+    }
+    {
+        ProfScope ps(f, PC_UPDATE_MISC);
+        hipLaunchKernelGGL(mean_update_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, f->Km, ld, n, m, f->yres,
+                           f->mu);
+    }
+}
+
+void launch_check_sigma(ekfvio_filter* f, float* d_out) {
+    hipLaunchKernelGGL(check_sigma_kernel, dim3(1), dim3(256), 0, f->stream, f->P, f->ldp, f->n, d_out);
+}

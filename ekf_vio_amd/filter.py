@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's `class TightlyCoupledEKF`
+(include/ekf_vio/TightlyCoupledEKF.h:25-68) over the C-ABI of libekfvio_hip.so.
+
+Same member names and argument meaning as the reference so that tests read like the
+reference's own (test/test_ekf.cpp, test/jacobian_test.cpp, test/analyzeEKFSimulation.cpp).
+All arithmetic happens in HIP kernels on the MI355X; this file only marshals buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+BASE_STATE_SIZE = 22
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class TightlyCoupledEKF:
+    def __init__(self, max_features=100, device=0, stream=None, predict_mode=capi.PREDICT_STRUCTURED,
+                 default_point_depth=0.5, default_point_depth_variance=100.0,
+                 default_point_homogenous_variance=1e-5, **cfg_overrides):
+        self.lib = capi.load()
+        cfg = capi.Config()
+        self._chk(self.lib.ekfvio_default_config(C.byref(cfg)))
+        cfg.max_features = max_features
+        cfg.predict_mode = predict_mode
+        cfg.default_point_depth = default_point_depth
+        cfg.default_point_depth_variance = default_point_depth_variance
+        cfg.default_point_homogenous_variance = default_point_homogenous_variance
+        for k, v in cfg_overrides.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.lib.ekfvio_create(C.byref(cfg), device, C.c_void_p(stream) if stream else None, C.byref(self.h))
+        if rc != capi.OK:
+            msg = self.lib.ekfvio_last_error(self.h).decode() if self.h else ""
+            raise capi.EkfvioError(rc, msg)
+
+    def _chk(self, rc, allow=()):
+        if rc != capi.OK and rc not in allow:
+            msg = self.lib.ekfvio_last_error(self.h).decode() if getattr(self, "h", None) else ""
+            raise capi.EkfvioError(rc, msg)
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ekfvio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference members -------------------------------------------------------------
+    def initializeBaseState(self):
+        self._chk(self.lib.ekfvio_reset(self.h))
+
+    def addNewFeatures(self, new_homogenous_features):
+        uv = np.ascontiguousarray(new_homogenous_features, dtype=np.float32).reshape(-1, 2)
+        self._chk(self.lib.ekfvio_add_features(self.h, _fp(uv), uv.shape[0]))
+
+    def process(self, dt):
+        self._chk(self.lib.ekfvio_process(self.h, float(dt)))
+
+    def numericallyLinearizeProcess(self, dt):
+        n = self.dim
+        F = np.zeros((n, n), dtype=np.float32)
+        self._chk(self.lib.ekfvio_linearize(self.h, float(dt), _fp(F)))
+        return F.T.copy()
+
+    def updateWithFeaturePositions(self, measured_positions, estimated_covariance, passed):
+        """Returns capi.OK or capi.ENUMERIC (non-positive Cholesky pivot; state still updated)."""
+        N = self.num_features
+        z = np.ascontiguousarray(measured_positions, dtype=np.float32).reshape(-1, 2)
+        R = np.ascontiguousarray(estimated_covariance, dtype=np.float32).reshape(-1, 4)
+        p = np.ascontiguousarray(passed, dtype=np.uint8).reshape(-1)
+        if not (z.shape[0] == R.shape[0] == p.shape[0]):
+            raise capi.EkfvioError(capi.EINVAL, "size mismatch")  # ROS_ASSERT :478
+        return self._chk(self.lib.ekfvio_update(self.h, _fp(z), _fp(R), _u8(p), p.shape[0]), allow=(capi.ENUMERIC,))
+
+    def formFeatureMeasurementMap(self, measured):
+        m = np.ascontiguousarray(measured, dtype=np.uint8)
+        idx = np.zeros(2 * len(m) + 1, dtype=np.int32)
+        rows = C.c_int32(0)
+        self._chk(self.lib.ekfvio_measurement_map(self.h, _u8(m), len(m), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  C.byref(rows)))
+        return idx[:rows.value].copy()
+
+    def previousFeaturePositionVector(self):
+        return self.get_state()["last_klt"]
+
+    def getFeatureHomogenousCovariance(self, index):
+        cov = np.zeros(4, np.float32)
+        self._chk(self.lib.ekfvio_get_feature_cov(self.h, index, _fp(cov)))
+        return cov.reshape(2, 2).T.copy()
+
+    def getFeatureDepthVariance(self, index):
+        v = C.c_float(0)
+        self._chk(self.lib.ekfvio_get_depth_variance(self.h, index, C.byref(v)))
+        return float(v.value)
+
+    def checkSigma(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._chk(self.lib.ekfvio_check_sigma(self.h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    # ---- state access ------------------------------------------------------------------
+    @property
+    def num_features(self):
+        return int(self.lib.ekfvio_num_features(self.h))
+
+    @property
+    def dim(self):
+        return int(self.lib.ekfvio_dim(self.h))
+
+    @property
+    def base_mu(self):
+        b = np.zeros(BASE_STATE_SIZE, np.float32)
+        self._chk(self.lib.ekfvio_get_base_mu(self.h, _fp(b)))
+        return b
+
+    @property
+    def Sigma(self):
+        n = self.dim
+        s = np.zeros((n, n), np.float32)
+        self._chk(self.lib.ekfvio_get_sigma(self.h, _fp(s), n))
+        return s.T.copy()
+
+    def get_state(self):
+        N = self.num_features
+        feat = np.zeros((N, 3), np.float32)
+        klt = np.zeros((N, 2), np.float32)
+        dele = np.zeros(N, np.uint8)
+        self._chk(self.lib.ekfvio_get_features(self.h, _fp(feat), _fp(klt), _u8(dele)))
+        return dict(base_mu=self.base_mu, feat_mu=feat, last_klt=klt, del_flag=dele, Sigma=self.Sigma)
+
+    def set_state(self, st):
+        base = np.ascontiguousarray(st["base_mu"], dtype=np.float32)
+        feat = np.ascontiguousarray(st["feat_mu"], dtype=np.float32).reshape(-1, 3)
+        N = feat.shape[0]
+        klt = np.ascontiguousarray(st["last_klt"], dtype=np.float32).reshape(N, 2)
+        dele = np.ascontiguousarray(st["del_flag"], dtype=np.uint8).reshape(N)
+        sig = np.ascontiguousarray(np.asarray(st["Sigma"], dtype=np.float32).T)
+        n = BASE_STATE_SIZE + 3 * N
+        self._chk(self.lib.ekfvio_set_state(self.h, N, _fp(base), _fp(feat), _fp(klt), _u8(dele), _fp(sig), n))
+
+    # ---- device-resident sequences -----------------------------------------------------
+    def upload_measurements(self, z, R, passed):
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        R = np.ascontiguousarray(R, dtype=np.float32)
+        p = np.ascontiguousarray(passed, dtype=np.uint8)
+        frames = p.shape[0]
+        self._chk(self.lib.ekfvio_upload_measurements(self.h, frames, _fp(z), _fp(R), _u8(p)))
+
+    def run_uploaded(self, first, count, dt):
+        self._chk(self.lib.ekfvio_run_uploaded(self.h, first, count, float(dt)))
+
+    def synchronize(self):
+        self._chk(self.lib.ekfvio_synchronize(self.h))
+
+    # ---- instrumentation ---------------------------------------------------------------
+    def profile(self, on):
+        self._chk(self.lib.ekfvio_profile_enable(self.h, int(on)))
+        if on:
+            self._chk(self.lib.ekfvio_profile_reset(self.h))
+
+    def profile_report(self):
+        out = {}
+        for c in range(self.lib.ekfvio_profile_count()):
+            ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+            self._chk(self.lib.ekfvio_profile_get(self.h, c, C.byref(ms), C.byref(n), C.byref(fl)))
+            out[self.lib.ekfvio_profile_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value)
+        return out
+
+    # ---- raw kernels -------------------------------------------------------------------
+    def test_gemm(self, A, B, C0, alpha=1.0, beta=0.0, transB=True):
+        """C = beta*C0 + alpha * A @ (B.T if transB else B); arrays are numpy [row, col]."""
+        A = np.asarray(A, np.float32)
+        B = np.asarray(B, np.float32)
+        M, K = A.shape
+        N = B.shape[0] if transB else B.shape[1]
+        Ac, Bc = np.ascontiguousarray(A.T), np.ascontiguousarray(B.T)  # column-major buffers
+        Cc = np.ascontiguousarray(np.asarray(C0, np.float32).T)
+        self._chk(self.lib.ekfvio_test_gemm(self.h, int(transB), M, N, K, alpha, _fp(Ac), M, _fp(Bc), B.shape[0], beta,
+                                            _fp(Cc), M))
+        return Cc.T.copy()
+
+    def test_cholesky_solve(self, S, Crhs):
+        """Returns (L, X = Crhs @ inv(S), info)."""
+        S = np.asarray(S, np.float32)
+        Crhs = np.asarray(Crhs, np.float32)
+        m, nr = S.shape[0], Crhs.shape[0]
+        Sc, Cc = np.ascontiguousarray(S.T), np.ascontiguousarray(Crhs.T)
+        L = np.zeros((m, m), np.float32)
+        X = np.zeros((m, nr), np.float32)
+        info = C.c_int32(0)
+        self._chk(self.lib.ekfvio_test_cholesky_solve(self.h, m, nr, _fp(Sc), _fp(Cc), _fp(L), _fp(X), C.byref(info)))
+        return L.T.copy(), X.T.copy(), info.value

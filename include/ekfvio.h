@@ -1,0 +1,168 @@
+/* include/ekfvio.h — C-ABI of libekfvio_hip.so, the MI355X (gfx950) backend for the
+ * per-frame hot path of k-sheridan/ekf_vio (predict -> KLT measure -> EKF update).
+ *
+ * The reference has no plugin/FFI layer: the seam is the public C++ surface of
+ * `class TightlyCoupledEKF` (include/ekf_vio/TightlyCoupledEKF.h:25-68) and
+ * `KLTTracker::findNewFeaturePositions` (include/ekf_vio/KLTTracker.h:88-90), both called
+ * only from `EKFVIO::addFrame` (include/ekf_vio/EKFVIO.cpp:139-219).  Every entry point
+ * below names the reference member it replaces.  Plain pointers and sizes only; the
+ * caller owns every host buffer; all device state (mean, dense covariance, image
+ * pyramids, work buffers) is owned by the opaque handle.  One handle = one HIP stream on
+ * one device; calls on one handle must be serialised by the caller; different handles are
+ * fully independent (no globals, no statics).
+ *
+ * Layouts: vectors of 2-D points are x,y interleaved f32 (std::vector<Eigen::Vector2f>);
+ * 2x2 covariances are column-major f32 (std::vector<Eigen::Matrix2f>); flags are one byte
+ * each (std::vector<bool>); dense matrices are column-major with an explicit leading
+ * dimension; images are 8-bit single channel with a row stride in bytes.
+ *
+ * Errors: the reference aborts through ROS_ASSERT or logs and continues.  Here every
+ * function returns an int status and never aborts or throws across the boundary.
+ */
+#ifndef EKFVIO_H_
+#define EKFVIO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKFVIO_BASE_STATE_SIZE 22 /* TightlyCoupledEKF.h:12 */
+
+enum {
+    EKFVIO_OK = 0,
+    EKFVIO_EINVAL = 1,   /* what the reference ROS_ASSERTs (size mismatch, dt < 0, null) */
+    EKFVIO_ENUMERIC = 2, /* Cholesky met a non-positive pivot (reference: ROS_ERROR_COND at
+                            TightlyCoupledEKF.cpp:579, then continues); state is still updated */
+    EKFVIO_ECAPACITY = 3,/* more landmarks than config.max_features */
+    EKFVIO_EDEVICE = 4,  /* HIP runtime failure; ekfvio_last_error() has the text */
+    EKFVIO_ESTATE = 5    /* call sequence error (e.g. KLT track before two frames exist) */
+};
+
+enum { EKFVIO_PREDICT_STRUCTURED = 0, /* exploits F = [[A,0],[B,D]] (nnz = 358+36N) */
+       EKFVIO_PREDICT_DENSE = 1       /* dense F P F^T through the MFMA GEMM (north-star form) */ };
+
+typedef struct ekfvio_filter ekfvio_filter; /* opaque */
+
+/* The handful of Params.h globals the hot path reads, as a plain struct. */
+typedef struct ekfvio_config {
+    int32_t max_features;                  /* capacity; NUM_FEATURES (Params.h:46) */
+    float default_point_depth;             /* Params.h:83, 0.5 */
+    float default_point_depth_variance;    /* Params.h:84, 100 */
+    float default_point_homogenous_variance; /* Params.h:86, 1e-5 */
+    int32_t predict_mode;                  /* EKFVIO_PREDICT_* */
+    /* KLT (KLTTracker.cpp:61-64, Params.h:33,36,103-104) */
+    int32_t klt_window_size;               /* WINDOW_SIZE 21 */
+    int32_t klt_max_pyramid_level;         /* MAX_PYRAMID_LEVEL 3 */
+    int32_t klt_max_iterations;            /* 30 */
+    float klt_epsilon;                     /* 0.01 */
+    float klt_min_eigen;                   /* KLT_MIN_EIGEN 1e-4 */
+    int32_t kill_pad;                      /* KILL_PAD 11 */
+    int32_t max_image_width;               /* device pyramid capacity */
+    int32_t max_image_height;
+    int32_t use_principal_point;           /* 0 reproduces Feature.h:60-66 (cx,cy ignored) */
+} ekfvio_config;
+
+/* Fills `cfg` with the reference defaults (Params.h D_* values). */
+int ekfvio_default_config(ekfvio_config* cfg);
+
+/* TightlyCoupledEKF::TightlyCoupledEKF() + initializeBaseState()
+ * (TightlyCoupledEKF.cpp:10-56).  `device` is a HIP device ordinal.  `stream` is an
+ * existing hipStream_t to enqueue on, or NULL to let the handle create its own. */
+int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out);
+int ekfvio_destroy(ekfvio_filter* f);
+/* initializeBaseState(): back to mu = [0,0,0,1,0...], Sigma diag [0x7,30x9,0.5x6], no landmarks. */
+int ekfvio_reset(ekfvio_filter* f);
+const char* ekfvio_last_error(const ekfvio_filter* f);
+
+/* addNewFeatures(std::vector<Eigen::Vector2f>) (TightlyCoupledEKF.cpp:58-94). */
+int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count);
+
+/* process(float dt) (TightlyCoupledEKF.cpp:96-121): FD linearisation, mean propagation,
+ * Sigma <- F Sigma F^T + Q(dt), flush below 1e-13. */
+int ekfvio_process(ekfvio_filter* f, float dt);
+
+/* numericallyLinearizeProcess (TightlyCoupledEKF.cpp:176-325): writes the dense n x n
+ * Jacobian (column-major, ld = n) to host memory.  Does not change the state. */
+int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense);
+
+/* updateWithFeaturePositions(z, R, pass) (TightlyCoupledEKF.cpp:475-628).  `count` must
+ * equal the number of landmarks (reference ROS_ASSERT at :478).  Entries of z/R for
+ * failed landmarks are ignored.  Returns EKFVIO_OK or EKFVIO_ENUMERIC. */
+int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count);
+
+/* formFeatureMeasurementMap (TightlyCoupledEKF.cpp:634-661): state index of the single 1.0
+ * in each row of H.  Writes 2*(#measured) ints, returns that count through *rows. */
+int ekfvio_measurement_map(const ekfvio_filter* f, const uint8_t* measured, int32_t count, int32_t* idx, int32_t* rows);
+
+/* previousFeaturePositionVector() (TightlyCoupledEKF.cpp:462-470) and the landmark records
+ * (Feature.h:41-46).  Any pointer may be NULL. */
+int ekfvio_num_features(const ekfvio_filter* f);
+int ekfvio_dim(const ekfvio_filter* f); /* 22 + 3N */
+int ekfvio_get_base_mu(ekfvio_filter* f, float base_mu[EKFVIO_BASE_STATE_SIZE]);
+int ekfvio_get_features(ekfvio_filter* f, float* mu3N, float* last_klt2N, uint8_t* delete_flagN);
+int ekfvio_get_sigma(ekfvio_filter* f, float* sigma, int32_t ld);
+/* getFeatureHomogenousCovariance / getFeatureDepthVariance (TightlyCoupledEKF.cpp:663-681). */
+int ekfvio_get_feature_cov(ekfvio_filter* f, int32_t index, float cov2x2[4]);
+int ekfvio_get_depth_variance(ekfvio_filter* f, int32_t index, float* var);
+/* checkSigma (TightlyCoupledEKF.cpp:699-714) as numbers: min diagonal, max |S_ij - S_ji|. */
+int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym);
+
+/* Checkpoint / teacher-forcing hook (the reference has none; its members are public). */
+int ekfvio_set_state(ekfvio_filter* f, int32_t n_features, const float* base_mu, const float* mu3N,
+                     const float* last_klt2N, const uint8_t* delete_flagN, const float* sigma, int32_t ld);
+
+/* ---- KLT (KLTTracker::findNewFeaturePositions, KLTTracker.cpp:29-95) ----------------- */
+/* Uploads a frame (Frame.h:25-41: image + intrinsics K row-major 3x3 as in CameraInfo.K),
+ * builds its pyramid and Scharr derivatives on the device and makes it the current frame;
+ * the former current frame becomes the previous one (frame_buffer depth 2, Params.h:58). */
+int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                          const float K[9]);
+/* Tracks every landmark from the previous into the current frame: reference points are the
+ * landmarks' last KLT results, initial guesses the EKF-predicted positions.  Outputs metric
+ * z (2N), metric R (4N, 1e-5 px^2 scaled by 1/fx^2, 1/fy^2), pass (N).  Host pointers; any may be NULL. */
+int ekfvio_klt_track(ekfvio_filter* f, float* z2N, float* R4N, uint8_t* passN);
+/* Pixel-space tracking of arbitrary points (calcOpticalFlowPyrLK semantics with
+ * OPTFLOW_USE_INITIAL_FLOW) between the two resident frames; for tests. */
+int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float* init_px, int32_t count,
+                            float* out_px, uint8_t* status);
+
+/* EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) without the ROS
+ * publishing: first frame only stores the image and stamp; later frames run
+ * process(dt = stamp - t), then KLT + update if landmarks exist.  Landmark replenishment
+ * (FAST) stays with the caller: add landmarks with ekfvio_add_features afterwards. */
+int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height,
+                      int32_t stride, const float K[9]);
+/* EKFVIO::imu_callback (EKFVIO.cpp:113-115) is a logging stub in the reference; kept so the
+ * node shim has somewhere to deliver IMU records.  No arithmetic. */
+int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float accel[3]);
+
+/* ---- device-resident measurement sequences (benchmark / replay) ---------------------- */
+/* Copies `frames` consecutive (z, R, pass) triples for the current landmark count to HBM. */
+int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z, const float* R, const uint8_t* pass);
+/* Runs process(dt) + update(frame i) for i = first .. first+count-1 (indices wrap modulo the
+ * uploaded frame count) with no host<->device traffic.  Asynchronous; pair with
+ * ekfvio_synchronize. */
+int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt);
+int ekfvio_synchronize(ekfvio_filter* f);
+
+/* ---- instrumentation ----------------------------------------------------------------- */
+/* Per-kernel-class device time accumulated with HIP events on the handle's stream while
+ * profiling is on.  Classes: see ekfvio_profile_name.  Times in milliseconds. */
+int ekfvio_profile_enable(ekfvio_filter* f, int32_t on);
+int ekfvio_profile_reset(ekfvio_filter* f);
+int ekfvio_profile_count(void);
+const char* ekfvio_profile_name(int32_t cls);
+int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t* launches, double* flops);
+
+/* Raw kernels for unit tests (column-major, device copies made internally). */
+int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
+                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc);
+int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
+                               float* L_out, float* X_out, int32_t* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKFVIO_H_ */
