@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — filter steps/s of the EKF-VIO hot path on MI355X.
+
+One step = process(dt) + updateWithFeaturePositions with every landmark measured
+(BASELINE.json metric).  Default workload at 1 GPU is config 2:
+N = 256 landmarks (n = 790 states, m = 512 measurement rows), dt = 1/30, synthetic
+closed-loop sequence, measurements resident in HBM before the timed region.
+For --gpus N > 1 every rank runs an independent sequence on its own GPU (the filter is
+sequential per step; the only shard is the sequence: replicas only, no collective on the
+data path) and value = total steps/s over all ranks.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def dist_setup(n_gpus, backend=None):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(x, world):
+    if world == 1:
+        return x
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def result_line(args, world, n_landmarks, elapsed, extra):
+    n, m = 22 + 3 * n_landmarks, 2 * n_landmarks
+    line = {
+        "metric": "filter steps/sec (predict+update)", "value": world * args.steps / elapsed, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "simLaunch-style closed loop: process(dt)+update per step, all landmarks measured, "
+                               "measurements resident in HBM (BASELINE config 2)" if n_landmarks == 256 else
+                               "synthetic closed loop, process(dt)+update per step",
+                   "landmarks": n_landmarks, "state_dim": n, "measurement_rows": m, "dt": 1.0 / 30.0,
+                   "sequences": world, "parallelism": "replicas (one independent sequence per GPU, no collective)",
+                   "predict": args.predict},
+    }
+    line.update(extra)
+    return line
+
+
+def selftest_dist(args):
+    """Exercises only the multi-rank plumbing (barrier, max-over-ranks, aggregation) with a
+    synthetic per-rank time; used by the gloo CPU test.  Computes nothing."""
+    world, rank, _ = dist_setup(args.gpus, backend="gloo")
+    barrier(world)
+    elapsed = max_over_ranks(0.5 + 0.25 * rank, world)
+    barrier(world)
+    if rank == 0:
+        print(json.dumps(result_line(args, world, args.landmarks, elapsed, {"selftest": True})))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(n_landmarks, dt, budget_steps):
+    """The oracle (line-faithful fp32 restatement of the reference filter) timed on ONE host
+    core: the reference is single-threaded (no threads/OpenMP in its CMakeLists)."""
+    from oracle import OracleFilter, set_threads
+    from ekf_vio_amd.sim import Scenario
+    set_threads(1)
+    sc = Scenario(n_landmarks, seed=0)
+    f = OracleFilter(np.float32)
+    f.add_new_features(sc.initial_features())
+    fr = list(sc.frames(2 + budget_steps))
+    for z, R, p in fr[:2]:
+        f.process(dt), f.update(z, R, p)
+    t0 = time.perf_counter()
+    for z, R, p in fr[2:]:
+        f.process(dt), f.update(z, R, p)
+    el = time.perf_counter() - t0
+    return {"value": budget_steps / el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of process+update at N=%d after a 2-step warm-up, fp32 oracle "
+                      "(oracle/ekf_oracle.hpp), 1 thread; %.1f s" % (budget_steps, n_landmarks, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--landmarks", type=int, default=256)
+    ap.add_argument("--predict", choices=["structured", "dense"], default="structured")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto ~10-30 s)")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--selftest-dist", action="store_true")
+    args = ap.parse_args()
+    if args.selftest_dist:
+        return selftest_dist(args)
+
+    import torch
+    from ekf_vio_amd import TightlyCoupledEKF, capi
+    from ekf_vio_amd.sim import Scenario
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    world, rank, local = dist_setup(args.gpus)
+    torch.cuda.set_device(local)
+    N = args.landmarks
+    sc = Scenario(N, seed=rank)
+    mode = capi.PREDICT_DENSE if args.predict == "dense" else capi.PREDICT_STRUCTURED
+    g = TightlyCoupledEKF(max_features=N, device=local, predict_mode=mode)
+    g.addNewFeatures(sc.initial_features())
+    total = args.warmup + args.steps
+    n_frames = min(total, 4096)  # longer runs wrap around the uploaded sequence
+    fr = list(sc.frames(n_frames))
+    g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+    dt = sc.dt
+    g.run_uploaded(0, args.warmup, dt)
+    g.synchronize()
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    g.run_uploaded(args.warmup, args.steps, dt)
+    g.synchronize()
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    md, ma = g.checkSigma()
+    st_ok = bool(np.isfinite(g.base_mu).all() and md >= 0)
+
+    extra = {"state_finite_and_psd_diag": st_ok}
+    if rank == 0:
+        # per-kernel-class device time with HIP events on the handle's stream
+        g.profile(True)
+        g.run_uploaded(0, args.profile_steps, dt)
+        g.synchronize()
+        rep = g.profile_report()
+        g.profile(False)
+        ge = rep["gemm_update"]
+        n, m_pad = 22 + 3 * N, ((2 * N + 63) // 64) * 64
+        flops_per_launch = 2.0 * n * n * m_pad
+        avg_ms = ge["ms"] / max(ge["launches"], 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        extra["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel (P-update GEMMs: Sigma - K W, T + G K^T)",
+                             "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                             "flops_per_launch": flops_per_launch, "avg_launch_us": avg_ms * 1e3}
+        extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
+        if world == 1 and not args.no_cpu_baseline:
+            steps = args.cpu_steps or max(3, int(round(12.0 * (256.0 / N) ** 3)))
+            extra["cpu_baseline"] = cpu_baseline(N, dt, steps)
+        print(json.dumps(result_line(args, world, N, elapsed, extra)))
+    g.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

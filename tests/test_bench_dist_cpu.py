@@ -1,0 +1,35 @@
+"""world_size-2 gloo rehearsal of bench.py's multi-rank plumbing (replicas only: barrier,
+max-over-ranks timing, whole-job aggregation).  No compute, no GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_gloo_aggregation():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100",
+           "--warmup", "5", "--selftest-dist"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 100
+    # max over ranks of (0.5, 0.75) = 0.75 s; value = 2 sequences * 100 steps / 0.75 s
+    assert abs(r["ms_per_step"] - 7.5) < 1e-6
+    assert abs(r["value"] - 2 * 100 / 0.75) < 1e-6
+
+
+def test_single_rank_selftest_line_has_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-dist", "--steps", "10"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in r
+    assert r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]

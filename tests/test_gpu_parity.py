@@ -1,0 +1,315 @@
+"""GPU parity tests: every call goes through the C-ABI of libekfvio_hip.so (ekf_vio_amd.filter
+mirrors the reference's TightlyCoupledEKF member names) and is compared with the CPU oracle
+on the same seeded inputs.
+
+Tolerance policy (measured on MI355X, see DESIGN.md "Parity"):
+  * bookkeeping (H map, landmark order, pass/delete flags, last KLT positions): bit-exact;
+  * process(dt): Jacobian, propagated means and covariance are BIT-EXACT against the fp32
+    oracle (same operation order, no FMA contraction, double-precision trig narrowed);
+  * update: teacher-forced single steps, gap(HIP, oracle-fp32) <= TF_FACTOR x
+    gap(oracle-fp32, oracle-fp64) + floor.  The fp64 run is the yardstick that says how much
+    of the result fp32 rounding order determines at all (the Cholesky vs LDL^T and GEMM
+    association differences are of that kind).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ekf_vio_amd import EkfvioError, TightlyCoupledEKF, capi
+from ekf_vio_amd.sim import Scenario
+from oracle import OracleFilter
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+UV3 = [[0.1, 0.1], [-0.1, -0.1], [0.1, -0.1]]
+TF_FACTOR = 20.0   # measured worst case ~10x (first update from the raw prior, N=100)
+MU_FLOOR = 2e-5
+SIG_FLOOR = 2e-6
+
+
+def relf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if np.size(a) else 0.0
+
+
+# ---------------------------------------------------------------- raw kernels
+@pytest.mark.parametrize("M,N,K,tb", [(64, 64, 16, True), (130, 70, 48, True), (200, 64, 64, False),
+                                      (257, 129, 80, False), (790, 790, 512, True), (1, 1, 16, True)])
+def test_gemm_against_fp64(M, N, K, tb):
+    g = TightlyCoupledEKF(max_features=4)
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    Cg = g.test_gemm(A, B, C0, alpha=-1.0, beta=1.0, transB=tb)
+    Bm = (B.T if tb else B).astype(np.float64)
+    ref = C0.astype(np.float64) - A.astype(np.float64) @ Bm
+    bound = 2e-7 * (np.abs(A).astype(np.float64) @ np.abs(Bm) + np.abs(C0))  # k-ordered fp32 fmaf chain
+    assert np.all(np.abs(Cg - ref) <= bound * max(1.0, K / 64))
+    g.close()
+
+
+def test_gemm_is_an_ordered_fmaf_chain():
+    """A = I with an asymmetric B catches a transposed C write; integers make it exact."""
+    g = TightlyCoupledEKF(max_features=4)
+    n = 96
+    B = (np.arange(n * n).reshape(n, n) % 17 - 5).astype(np.float32)
+    C = g.test_gemm(np.eye(n, dtype=np.float32), B, np.zeros((n, n), np.float32), transB=False)
+    assert np.array_equal(C, B)
+    C = g.test_gemm(np.eye(n, dtype=np.float32), B, np.zeros((n, n), np.float32), transB=True)
+    assert np.array_equal(C, B.T)
+    g.close()
+
+
+@pytest.mark.parametrize("m,nr", [(2, 25), (64, 30), (130, 100), (512, 790)])
+def test_cholesky_and_right_solve(m, nr):
+    g = TightlyCoupledEKF(max_features=4)
+    rng = np.random.default_rng(m)
+    Q = rng.standard_normal((m, m))
+    S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
+    Cr = rng.standard_normal((nr, m)).astype(np.float32)
+    L, X, info = g.test_cholesky_solve(S, Cr)
+    assert info == 0
+    S64 = S.astype(np.float64)
+    assert relf(np.tril(L), np.linalg.cholesky(S64)) < 2e-6
+    assert relf(X, Cr.astype(np.float64) @ np.linalg.inv(S64)) < 2e-5
+    g.close()
+
+
+def test_cholesky_flags_non_positive_pivot():
+    g = TightlyCoupledEKF(max_features=4)
+    S = np.eye(8, dtype=np.float32)
+    S[3, 3] = -1.0
+    _, _, info = g.test_cholesky_solve(S, np.ones((4, 8), np.float32))
+    assert info == 1
+    g.close()
+
+
+# ---------------------------------------------------------------- known answers through the ABI
+def test_h_map_known_answer_through_abi():
+    """test/test_ekf.cpp:44-63."""
+    g = TightlyCoupledEKF(max_features=8)
+    g.addNewFeatures(UV3)
+    idx = g.formFeatureMeasurementMap(GOLD["h_map"]["measured"])
+    assert g.dim == GOLD["h_map"]["cols"]
+    assert [[r, int(c)] for r, c in enumerate(idx)] == GOLD["h_map"]["ones_at"]
+    g.close()
+
+
+def test_initial_state_and_feature_insertion_bit_exact():
+    g, o = TightlyCoupledEKF(max_features=16), OracleFilter(np.float32)
+    assert np.array_equal(g.base_mu, o.get_state()["base_mu"])
+    g.addNewFeatures(UV3), o.add_new_features(UV3)
+    g.addNewFeatures([]), o.add_new_features(np.zeros((0, 2)))  # early return :59
+    more = [[0.3, -0.2], [0.0, 0.25]]
+    g.addNewFeatures(more), o.add_new_features(more)
+    sg, so = g.get_state(), o.get_state()
+    for k in ("base_mu", "feat_mu", "last_klt", "del_flag", "Sigma"):
+        assert np.array_equal(sg[k], so[k]), k
+    assert np.array_equal(np.diag(sg["Sigma"])[:31], np.array(GOLD["sigma0_diag_3feat"], np.float32))
+    assert g.getFeatureDepthVariance(1) == 100.0
+    assert np.array_equal(g.getFeatureHomogenousCovariance(0), np.diag([1e-5, 1e-5]).astype(np.float32))
+    g.close()
+
+
+def test_error_codes_replace_asserts():
+    g = TightlyCoupledEKF(max_features=4)
+    g.addNewFeatures(UV3)
+    with pytest.raises(EkfvioError) as e:
+        g.addNewFeatures([[0, 0], [1, 1]])
+    assert e.value.code == capi.ECAPACITY
+    with pytest.raises(EkfvioError) as e:
+        g.process(-0.1)  # ROS_ASSERT(dt >= 0), EKFVIO.cpp:162
+    assert e.value.code == capi.EINVAL
+    with pytest.raises(EkfvioError) as e:
+        g.updateWithFeaturePositions(np.zeros((2, 2)), np.zeros((2, 4)), [1, 1])  # ROS_ASSERT :478
+    assert e.value.code == capi.EINVAL
+    g.close()
+
+
+def test_jacobian_scenarios_bit_exact():
+    """jacobian_test.cpp:34-47 inputs (omega_x = 3.1415, b_dx = 1, dt = 0.1 / 0.0)."""
+    g, o = TightlyCoupledEKF(max_features=8), OracleFilter(np.float32, emulate_static_cache=False)
+    g.addNewFeatures(UV3), o.add_new_features(UV3)
+    for om, vx, dt in [(0.0, 0.0, 0.1), (0.0, 0.0, 0.0), (3.1415, 0.0, 0.1), (3.1415, 1.0, 0.1), (3.1415, 1.0, 0.0)]:
+        st = o.get_state()
+        st["base_mu"][10], st["base_mu"][7] = om, vx
+        o.set_state(st), g.set_state(st)
+        assert np.array_equal(g.numericallyLinearizeProcess(dt), o.linearize(dt)), (om, vx, dt)
+    g.close()
+
+
+def test_motion_model_golden_scenarios():
+    """test/test_ekf.cpp:154-204 inputs; expected values tests/golden/kat.json (fp64-derived)."""
+    g = TightlyCoupledEKF(max_features=4)
+    for sc in GOLD["scenarios"]:
+        st = dict(base_mu=np.array(sc["base_mu"], np.float32), feat_mu=np.array([sc["feature"]], np.float32),
+                  last_klt=np.zeros((1, 2), np.float32), del_flag=np.zeros(1, np.uint8), Sigma=np.eye(25, dtype=np.float32))
+        g.set_state(st)
+        g.process(sc["dt"])
+        out = g.get_state()
+        assert np.allclose(out["base_mu"], sc["base_out"], rtol=0, atol=3e-6), sc["name"]
+        assert np.allclose(out["feat_mu"][0], sc["feature_out"], rtol=0, atol=1.2e-5), sc["name"]
+    g.close()
+
+
+# ---------------------------------------------------------------- teacher-forced steps
+@pytest.mark.parametrize("N,steps", [(3, 6), (30, 20), (100, 12)])
+def test_teacher_forced_process_bit_exact_and_update_within_fp64_yardstick(N, steps):
+    sc = Scenario(N, seed=0, dt=0.05)
+    g = TightlyCoupledEKF(max_features=N)
+    o32, o64 = OracleFilter(np.float32), OracleFilter(np.float64)
+    uv = sc.initial_features()
+    g.addNewFeatures(uv), o32.add_new_features(uv), o64.add_new_features(uv)
+    for s, (z, R, p) in enumerate(sc.frames(steps)):
+        p = p.copy()
+        if N >= 30 and s % 3 == 1:
+            p[(s * 7) % N] = 0
+            p[(s * 11 + 3) % N] = 0
+        st = o32.get_state()
+        g.set_state(st)
+        g.process(sc.dt), o32.process(sc.dt)
+        sg, so = g.get_state(), o32.get_state()
+        for k in ("base_mu", "feat_mu", "Sigma"):
+            assert np.array_equal(sg[k], so[k]), ("process", s, k)
+        st = o32.get_state()
+        g.set_state(st), o64.set_state(st)
+        rc = g.updateWithFeaturePositions(z, R, p)
+        assert rc == capi.OK
+        assert o32.update(z, R, p) == 0
+        o64.update(z, R, p)
+        sg, s32, s64 = g.get_state(), o32.get_state(), o64.get_state()
+        assert np.array_equal(sg["del_flag"], s32["del_flag"]) and np.array_equal(sg["last_klt"], s32["last_klt"])
+        for k, floor in (("base_mu", MU_FLOOR), ("feat_mu", MU_FLOOR)):
+            assert maxabs(sg[k], s32[k]) <= TF_FACTOR * maxabs(s32[k], s64[k]) + floor, ("update", s, k)
+        assert relf(sg["Sigma"], s32["Sigma"]) <= TF_FACTOR * relf(s32["Sigma"], s64["Sigma"]) + SIG_FLOOR, ("update", s)
+        assert abs(np.linalg.norm(sg["base_mu"][3:7]) - 1) < 1e-6
+    g.close()
+
+
+def test_update_edge_cases_bookkeeping():
+    """none / one / all landmarks measured; failed ones are only flagged (:528), never removed."""
+    N = 12
+    sc = Scenario(N, seed=5, dt=0.05)
+    g, o = TightlyCoupledEKF(max_features=N), OracleFilter(np.float32)
+    uv = sc.initial_features()
+    g.addNewFeatures(uv), o.add_new_features(uv)
+    masks = [np.zeros(N, np.uint8), np.eye(N, dtype=np.uint8)[4], np.ones(N, np.uint8), np.zeros(N, np.uint8)]
+    for mask, (z, R, _) in zip(masks, sc.frames(len(masks))):
+        st = o.get_state()
+        g.set_state(st)
+        g.process(sc.dt), o.process(sc.dt)
+        st = o.get_state()
+        g.set_state(st)
+        assert g.updateWithFeaturePositions(z, R, mask) == capi.OK
+        o.update(z, R, mask)
+        sg, so = g.get_state(), o.get_state()
+        assert np.array_equal(sg["del_flag"], so["del_flag"]) and np.array_equal(sg["last_klt"], so["last_klt"])
+        assert g.num_features == N
+        assert maxabs(sg["base_mu"], so["base_mu"]) < 2e-3 and relf(sg["Sigma"], so["Sigma"]) < 1e-3
+        if mask.sum() == 0:  # empty measurement: Sigma untouched, quaternion renormalised (:605-609)
+            assert np.array_equal(sg["Sigma"], st["Sigma"])
+    g.close()
+
+
+def test_process_without_landmarks():
+    g, o = TightlyCoupledEKF(max_features=4), OracleFilter(np.float32)
+    st = o.get_state()
+    st["base_mu"][7:13] = (0.3, -0.1, 0.2, 0.05, -0.3, 0.1)
+    o.set_state(st), g.set_state(st)
+    for dt in (0.1, 0.02, 0.0):
+        g.process(dt), o.process(dt)
+        sg, so = g.get_state(), o.get_state()
+        assert np.array_equal(sg["base_mu"], so["base_mu"]) and np.array_equal(sg["Sigma"], so["Sigma"])
+    g.close()
+
+
+# ---------------------------------------------------------------- free-running loops
+@pytest.mark.parametrize("N", [30, 100])
+def test_free_running_after_warm_start(N):
+    """Free-running 25 steps from a converged state; bound = multiple of the oracle's own
+    fp32-vs-fp64 drift over the same steps.  (From the raw prior the first updates have
+    cond(S) ~ 1e7 and ANY two fp32 evaluation orders decorrelate: see DESIGN.md.)"""
+    sc = Scenario(N, seed=1, dt=0.05)
+    g = TightlyCoupledEKF(max_features=N)
+    o32, o64 = OracleFilter(np.float32), OracleFilter(np.float64)
+    uv = sc.initial_features()
+    o64.add_new_features(uv)
+    it = sc.frames(45)
+    for _ in range(20):
+        z, R, p = next(it)
+        o64.process(sc.dt), o64.update(z, R, p)
+    st = o64.get_state()
+    st32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in st.items()}
+    g.set_state(st32), o32.set_state(st32)
+    worst = dict(mu=0.0, sig=0.0, mu_y=0.0, sig_y=0.0)
+    for z, R, p in it:
+        for f in (g, o32, o64):
+            f.process(sc.dt)
+        g.updateWithFeaturePositions(z, R, p), o32.update(z, R, p), o64.update(z, R, p)
+        sg, s32, s64 = g.get_state(), o32.get_state(), o64.get_state()
+        worst["mu"] = max(worst["mu"], maxabs(sg["base_mu"], s32["base_mu"]))
+        worst["mu_y"] = max(worst["mu_y"], maxabs(s32["base_mu"], s64["base_mu"]))
+        worst["sig"] = max(worst["sig"], relf(sg["Sigma"], s32["Sigma"]))
+        worst["sig_y"] = max(worst["sig_y"], relf(s32["Sigma"], s64["Sigma"]))
+    assert worst["mu"] <= 5 * worst["mu_y"] + 1e-4, worst
+    assert worst["sig"] <= 5 * worst["sig_y"] + 1e-3, worst
+    assert maxabs(g.base_mu[:3], sc.pos) < 0.02 and maxabs(g.base_mu[7:10], sc.vel) < 0.02
+    g.close()
+
+
+@pytest.mark.parametrize("N,frames", [(256, 60), (1024, 8)])
+def test_full_size_properties(N, frames):
+    """BASELINE configs 2 and 3 at full size, through the device-resident sequence path:
+    size-independent properties (checkSigma invariants :699-714, unit quaternion, truth
+    tracking, determinism)."""
+    sc = Scenario(N, seed=0)
+    g = TightlyCoupledEKF(max_features=N)
+    g.addNewFeatures(sc.initial_features())
+    fr = list(sc.frames(frames))
+    z, R, p = (np.stack([f[i] for f in fr]) for i in range(3))
+    g.upload_measurements(z, R, p)
+    g.run_uploaded(0, frames, sc.dt)
+    g.synchronize()
+    md, ma = g.checkSigma()
+    st = g.get_state()
+    assert np.isfinite(st["Sigma"]).all() and np.isfinite(st["base_mu"]).all()
+    assert md >= 0 and ma <= 2e-2
+    assert abs(np.linalg.norm(st["base_mu"][3:7]) - 1) < 1e-6
+    assert st["del_flag"].sum() == 0 and np.array_equal(st["last_klt"], z[-1])
+    if frames >= 30:
+        assert maxabs(st["base_mu"][:3], sc.pos) < 0.02 and maxabs(st["base_mu"][7:10], sc.vel) < 0.02
+    # determinism: the same sequence from the same start gives the same bits
+    g.initializeBaseState()
+    g.addNewFeatures(sc.initial_features())
+    g.run_uploaded(0, frames, sc.dt)
+    g.synchronize()
+    st2 = g.get_state()
+    assert np.array_equal(st["Sigma"], st2["Sigma"]) and np.array_equal(st["base_mu"], st2["base_mu"])
+    g.close()
+
+
+def test_dense_predict_matches_structured():
+    """F P F^T through the MFMA GEMM (north-star dense form) against the structured kernel."""
+    N = 40
+    sc = Scenario(N, seed=2, dt=0.05)
+    a = TightlyCoupledEKF(max_features=N, predict_mode=capi.PREDICT_STRUCTURED)
+    b = TightlyCoupledEKF(max_features=N, predict_mode=capi.PREDICT_DENSE)
+    o = OracleFilter(np.float64)
+    o.add_new_features(sc.initial_features())
+    for z, R, p in sc.frames(10):
+        o.process(sc.dt), o.update(z, R, p)
+    st = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in o.get_state().items()}
+    a.set_state(st), b.set_state(st)
+    a.process(sc.dt), b.process(sc.dt)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa["base_mu"], sb["base_mu"]) and np.array_equal(sa["feat_mu"], sb["feat_mu"])
+    assert relf(sb["Sigma"], sa["Sigma"]) < 2e-6
+    a.close(), b.close()
