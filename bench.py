@@ -176,7 +176,7 @@ def main():
                              "flops_per_launch": flops_per_launch, "avg_launch_us": avg_ms * 1e3}
         extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
         if world == 1 and not args.no_cpu_baseline:
-            steps = args.cpu_steps or max(3, int(round(12.0 * (256.0 / N) ** 3)))
+            steps = args.cpu_steps or max(3, int(round(60.0 * (256.0 / N) ** 3)))
             extra["cpu_baseline"] = cpu_baseline(N, dt, steps)
         print(json.dumps(result_line(args, world, N, elapsed, extra)))
     g.close()

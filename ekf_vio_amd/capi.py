@@ -48,10 +48,10 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB_PATH):
+    if not os.path.exists(_build.LIB_PATH) or _build._stale():
         if not build_if_missing:
             raise FileNotFoundError(_build.LIB_PATH + " not built; run python -m ekf_vio_amd._build")
-        _build.build()
+        _build.build()  # hipcc cross-compiles gfx950 with or without a GPU present
     lib = C.CDLL(_build.LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     fp, u8p, ip = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)

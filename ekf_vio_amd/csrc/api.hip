@@ -16,10 +16,12 @@
     } while (0)
 
 namespace {
+// Allocation + zero fill ordered on the handle's (non-blocking) stream: nothing in this
+// library relies on the legacy null stream, which a non-blocking stream does not wait for.
 template <class T>
-hipError_t dev_alloc(T** p, size_t count) {
+hipError_t dev_alloc(hipStream_t s, T** p, size_t count) {
     hipError_t e = hipMalloc((void**)p, sizeof(T) * (count ? count : 1));
-    if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(T) * (count ? count : 1));
+    if (e == hipSuccess) e = hipMemsetAsync(*p, 0, sizeof(T) * (count ? count : 1), s);
     return e;
 }
 
@@ -105,29 +107,29 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     f->ldp = round_up(f->n_cap, 64);
     f->m_cap = round_up(2 * maxf > 0 ? 2 * maxf : 1, 64);
     const size_t pp = (size_t)f->ldp * f->ldp, pm = (size_t)f->ldp * f->m_cap, mm = (size_t)f->m_cap * f->m_cap;
-    HIPC(f, dev_alloc(&f->mu, f->ldp));
-    HIPC(f, dev_alloc(&f->mu_next, f->ldp));
-    HIPC(f, dev_alloc(&f->last_klt, 2 * (size_t)maxf));
-    HIPC(f, dev_alloc(&f->del_flag, (size_t)maxf));
-    HIPC(f, dev_alloc(&f->P, pp));
-    HIPC(f, dev_alloc(&f->P2, pp));
-    HIPC(f, dev_alloc(&f->FA, EKF_BASE * EKF_BASE));
-    HIPC(f, dev_alloc(&f->FB, 27 * (size_t)maxf));
-    HIPC(f, dev_alloc(&f->FD, 9 * (size_t)maxf));
-    HIPC(f, dev_alloc(&f->Fdense, pp));
-    HIPC(f, dev_alloc(&f->idx, (size_t)f->m_cap));
-    HIPC(f, dev_alloc(&f->zmeas, 2 * (size_t)maxf));
-    HIPC(f, dev_alloc(&f->Rmeas, 4 * (size_t)maxf));
-    HIPC(f, dev_alloc(&f->pass, (size_t)maxf));
-    HIPC(f, dev_alloc(&f->yres, (size_t)f->m_cap));
-    HIPC(f, dev_alloc(&f->Rm, 2 * (size_t)f->m_cap));
-    HIPC(f, dev_alloc(&f->S, mm));
-    HIPC(f, dev_alloc(&f->L, mm));
-    HIPC(f, dev_alloc(&f->Linv, 64 * (size_t)f->m_cap));
-    HIPC(f, dev_alloc(&f->Km, pm));
-    HIPC(f, dev_alloc(&f->Wt, pm));
-    HIPC(f, dev_alloc(&f->Gm, pm));
-    HIPC(f, dev_alloc(&f->info, 4));
+    HIPC(f, dev_alloc(f->stream, &f->mu, f->ldp));
+    HIPC(f, dev_alloc(f->stream, &f->mu_next, f->ldp));
+    HIPC(f, dev_alloc(f->stream, &f->last_klt, 2 * (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->del_flag, (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->P, pp));
+    HIPC(f, dev_alloc(f->stream, &f->P2, pp));
+    HIPC(f, dev_alloc(f->stream, &f->FA, EKF_BASE * EKF_BASE));
+    HIPC(f, dev_alloc(f->stream, &f->FB, 27 * (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->FD, 9 * (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->Fdense, pp));
+    HIPC(f, dev_alloc(f->stream, &f->idx, (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->zmeas, 2 * (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->Rmeas, 4 * (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->pass, (size_t)maxf));
+    HIPC(f, dev_alloc(f->stream, &f->yres, (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->Rm, 2 * (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->S, mm));
+    HIPC(f, dev_alloc(f->stream, &f->L, mm));
+    HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->Km, pm));
+    HIPC(f, dev_alloc(f->stream, &f->Wt, pm));
+    HIPC(f, dev_alloc(f->stream, &f->Gm, pm));
+    HIPC(f, dev_alloc(f->stream, &f->info, 4));
     HIPC(f, hipHostMalloc((void**)&f->h_info, 4 * sizeof(int), hipHostMallocDefault));
     HIPC(f, hipEventCreate(&f->ev0));
     HIPC(f, hipEventCreate(&f->ev1));
@@ -344,12 +346,13 @@ int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z,
     f->seq_z = f->seq_R = nullptr;
     f->seq_pass = nullptr;
     const size_t N = f->N;
-    HIPC(f, dev_alloc(&f->seq_z, frames * 2 * N));
-    HIPC(f, dev_alloc(&f->seq_R, frames * 4 * N));
-    HIPC(f, dev_alloc(&f->seq_pass, frames * N));
-    HIPC(f, hipMemcpy(f->seq_z, z, sizeof(float) * frames * 2 * N, hipMemcpyHostToDevice));
-    HIPC(f, hipMemcpy(f->seq_R, R, sizeof(float) * frames * 4 * N, hipMemcpyHostToDevice));
-    HIPC(f, hipMemcpy(f->seq_pass, pass, frames * N, hipMemcpyHostToDevice));
+    HIPC(f, dev_alloc(f->stream, &f->seq_z, frames * 2 * N));
+    HIPC(f, dev_alloc(f->stream, &f->seq_R, frames * 4 * N));
+    HIPC(f, dev_alloc(f->stream, &f->seq_pass, frames * N));
+    HIPC(f, hipMemcpyAsync(f->seq_z, z, sizeof(float) * frames * 2 * N, hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpyAsync(f->seq_R, R, sizeof(float) * frames * 4 * N, hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpyAsync(f->seq_pass, pass, frames * N, hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
     f->seq_frames = frames;
     f->seq_N = (int)N;
     f->seq_m.resize(frames);
@@ -404,20 +407,29 @@ int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int
                      int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc) {
     if (!f || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
-    // device copies padded to the kernel's contract (64-row/col slack, K to 16, zero fill)
+    // device copies padded to the kernel's contract (64-row/col slack, K to 16, zero fill);
+    // packed on the host so that only flat copies are issued
     const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 16);
     const int brows = transB ? Np : Kp, bcols = transB ? Kp : Np;
+    std::vector<float> hA((size_t)Mp * Kp, 0.f), hB((size_t)brows * bcols, 0.f), hC((size_t)Mp * Np, 0.f);
+    for (int k = 0; k < K; k++)
+        for (int i = 0; i < M; i++) hA[(size_t)k * Mp + i] = A[(size_t)k * lda + i];
+    for (int c = 0; c < (transB ? K : N); c++)
+        for (int r = 0; r < (transB ? N : K); r++) hB[(size_t)c * brows + r] = B[(size_t)c * ldb + r];
+    for (int j = 0; j < N; j++)
+        for (int i = 0; i < M; i++) hC[(size_t)j * Mp + i] = C[(size_t)j * ldc + i];
     float *dA, *dB, *dC;
-    HIPC(f, dev_alloc(&dA, (size_t)Mp * Kp));
-    HIPC(f, dev_alloc(&dB, (size_t)brows * bcols));
-    HIPC(f, dev_alloc(&dC, (size_t)Mp * Np));
-    HIPC(f, hipMemcpy2D(dA, sizeof(float) * Mp, A, sizeof(float) * lda, sizeof(float) * M, K, hipMemcpyHostToDevice));
-    HIPC(f, hipMemcpy2D(dB, sizeof(float) * brows, B, sizeof(float) * ldb, sizeof(float) * (transB ? N : K),
-                        transB ? K : N, hipMemcpyHostToDevice));
-    HIPC(f, hipMemcpy2D(dC, sizeof(float) * Mp, C, sizeof(float) * ldc, sizeof(float) * M, N, hipMemcpyHostToDevice));
+    HIPC(f, dev_alloc(f->stream, &dA, hA.size()));
+    HIPC(f, dev_alloc(f->stream, &dB, hB.size()));
+    HIPC(f, dev_alloc(f->stream, &dC, hC.size()));
+    HIPC(f, hipMemcpyAsync(dA, hA.data(), sizeof(float) * hA.size(), hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpyAsync(dB, hB.data(), sizeof(float) * hB.size(), hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpyAsync(dC, hC.data(), sizeof(float) * hC.size(), hipMemcpyHostToDevice, f->stream));
     launch_gemm(f->stream, transB, M, N, Kp, alpha, dA, Mp, dB, brows, beta, dC, Mp, dC, Mp, 0);
+    HIPC(f, hipMemcpyAsync(hC.data(), dC, sizeof(float) * hC.size(), hipMemcpyDeviceToHost, f->stream));
     HIPC(f, hipStreamSynchronize(f->stream));
-    HIPC(f, hipMemcpy2D(C, sizeof(float) * ldc, dC, sizeof(float) * Mp, sizeof(float) * M, N, hipMemcpyDeviceToHost));
+    for (int j = 0; j < N; j++)
+        for (int i = 0; i < M; i++) C[(size_t)j * ldc + i] = hC[(size_t)j * Mp + i];
     hipFree(dA);
     hipFree(dB);
     hipFree(dC);
@@ -431,25 +443,28 @@ int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const 
     HIPC(f, hipSetDevice(f->device));
     const int mp = round_up(m, 64), rp = round_up(nrhs, 64);
     float *dS, *dL, *dLi, *dX, *dW;
-    HIPC(f, dev_alloc(&dS, (size_t)mp * mp));
-    HIPC(f, dev_alloc(&dL, (size_t)mp * mp));
-    HIPC(f, dev_alloc(&dLi, (size_t)64 * mp));
-    HIPC(f, dev_alloc(&dX, (size_t)rp * mp));
-    HIPC(f, dev_alloc(&dW, (size_t)rp * mp));
+    HIPC(f, dev_alloc(f->stream, &dS, (size_t)mp * mp));
+    HIPC(f, dev_alloc(f->stream, &dL, (size_t)mp * mp));
+    HIPC(f, dev_alloc(f->stream, &dLi, (size_t)64 * mp));
+    HIPC(f, dev_alloc(f->stream, &dX, (size_t)rp * mp));
+    HIPC(f, dev_alloc(f->stream, &dW, (size_t)rp * mp));
     std::vector<float> hs((size_t)mp * mp, 0.f);
     for (int c = 0; c < mp; c++)
         for (int r = 0; r < mp; r++) hs[(size_t)c * mp + r] = (r < m && c < m) ? S[(size_t)c * m + r] : (r == c ? 1.f : 0.f);
-    HIPC(f, hipMemcpy(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice));
-    HIPC(f, hipMemcpy2D(dX, sizeof(float) * rp, Crhs, sizeof(float) * nrhs, sizeof(float) * nrhs, m, hipMemcpyHostToDevice));
+    HIPC(f, hipMemcpyAsync(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpy2DAsync(dX, sizeof(float) * rp, Crhs, sizeof(float) * nrhs, sizeof(float) * nrhs, m,
+                             hipMemcpyHostToDevice, f->stream));
     launch_cholesky(f, dS, dL, dLi, mp, mp);
     launch_solve_right(f, dL, dLi, mp, mp, dX, dW, nrhs, rp);
-    HIPC(f, hipStreamSynchronize(f->stream));
-    if (L_out) HIPC(f, hipMemcpy2D(L_out, sizeof(float) * m, dL, sizeof(float) * mp, sizeof(float) * m, m, hipMemcpyDeviceToHost));
-    if (X_out) HIPC(f, hipMemcpy2D(X_out, sizeof(float) * nrhs, dX, sizeof(float) * rp, sizeof(float) * nrhs, m, hipMemcpyDeviceToHost));
+    if (L_out) HIPC(f, hipMemcpy2DAsync(L_out, sizeof(float) * m, dL, sizeof(float) * mp, sizeof(float) * m, m,
+                                        hipMemcpyDeviceToHost, f->stream));
+    if (X_out) HIPC(f, hipMemcpy2DAsync(X_out, sizeof(float) * nrhs, dX, sizeof(float) * rp, sizeof(float) * nrhs, m,
+                                        hipMemcpyDeviceToHost, f->stream));
     if (info) {
-        HIPC(f, hipMemcpy(info, f->info, sizeof(int), hipMemcpyDeviceToHost));
-        HIPC(f, hipMemset(f->info, 0, sizeof(int)));
+        HIPC(f, hipMemcpyAsync(info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
     }
+    HIPC(f, hipStreamSynchronize(f->stream));
     hipFree(dS);
     hipFree(dL);
     hipFree(dLi);

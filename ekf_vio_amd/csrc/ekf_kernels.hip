@@ -363,8 +363,13 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
     }
 }
 
-// S = H Sigma H^T + R (:559-561), padded with the identity; C = Sigma H^T (columns of
-// Sigma); Wt = (H Sigma)^T (rows of Sigma, transposed so that it is state-major).
+// A = (H Sigma H^T + R)^T (:559-561, :578), padded with the identity.  The reference hands
+// S.transpose() to SimplicialLDLT, which reads the LOWER triangle of what it is given, i.e.
+// the UPPER triangle of S.  Sigma is only symmetric to rounding (~1e-6) and S^-1 amplifies
+// by 1/lambda_min ~ 5e4, so the choice of triangle is visible at the 1e-4 level: store
+// A(r,c) = S(c,r) so that the Cholesky kernels (which read the lower triangle) factor the
+// same numbers as the reference.  C = Sigma H^T (columns of Sigma); Wt = (H Sigma)^T (rows
+// of Sigma, transposed so that it is state-major).
 __global__ __launch_bounds__(256) void gather_S_kernel(const float* __restrict__ P, int ld, const int* __restrict__ idx,
                                                        const float* __restrict__ Rm, int m, int m_pad, float* S,
                                                        int lds) {
@@ -373,11 +378,11 @@ __global__ __launch_bounds__(256) void gather_S_kernel(const float* __restrict__
     if (r >= m_pad) return;
     float v;
     if (r < m && c < m) {
-        v = P[(size_t)idx[c] * ld + idx[r]];
+        v = P[(size_t)idx[r] * ld + idx[c]];  // Sigma(idx[c], idx[r]) = S(c,r)
         if (r == c)
             v = v + Rm[2 * r];
         else if ((r ^ 1) == c)
-            v = v + Rm[2 * c + 1];  // off-diagonal element of column c
+            v = v + Rm[2 * r + 1];  // R(c,r): the off-diagonal element of column r
     } else {
         v = (r == c) ? 1.f : 0.f;
     }
