@@ -1,53 +1,168 @@
-// ekf_vio_amd/csrc/chol.hip — blocked Cholesky of the innovation covariance S and the
-// right-hand triangular solves that turn Sigma*H^T into the Kalman gain.
+// ekf_vio_amd/csrc/chol.hip — blocked Cholesky of the innovation covariance and the
+// right-hand triangular sweeps that turn Sigma*H^T into the Kalman gain.
 //
 // Reference: SimplicialLDLT(S^T) + solve, TightlyCoupledEKF.cpp:577-580
-//   K = (S^-T (Sigma H^T)^T)^T  ==  (Sigma H^T) S^-1.
-// Here: S = L L^T by a right-looking blocked factorisation with 64-wide blocks.  The
-// diagonal block is factored inside one workgroup in LDS (potrf64_kernel, which also
-// forms the inverse of the 64x64 triangular factor); panel solves and trailing updates
-// are fp32 MFMA GEMMs against those inverses.  K = ((Sigma H^T) L^-T) L^-1 is two blocked
-// substitutions whose block steps are GEMMs as well.
+//   K = (S^-T (Sigma H^T)^T)^T  ==  (Sigma H^T) A^-1,  A = sym(lower(S^T)).
+// Here A = L L^T by a right-looking blocked factorisation with 64-wide blocks, one launch
+// per block step:
+//   chol_step_kernel(k): every workgroup owns one 64x64 tile (i,j), i >= j > k, of the
+//     trailing matrix: it forms the panel blocks L_ik = A_ik L_kk^-T and L_jk, applies
+//     A_ij -= L_ik L_jk^T, and the workgroup that owns the next diagonal tile (k+1,k+1)
+//     immediately factors it in LDS (look-ahead), so the sequential chain is one launch per
+//     block step.
+//   K = ((Sigma H^T) L^-T) L^-1 by two blocked substitutions, again one launch per block
+//     step (diagonal-block solve + trailing update fused).
+//
+// Triangular solves against a 64x64 diagonal block are micro-blocked substitutions with
+// 16-wide blocks: each wavefront owns 16 rows of the right-hand side in LDS and alternates
+// "multiply by the inverse of a 16x16 diagonal block" and "eliminate from the remaining
+// columns", both on v_mfma_f32_16x16x4_f32, with no workgroup barrier (rows never cross
+// wavefronts).  Only 16x16 inverses are ever formed, in fp64 from the fp32 factor and
+// rounded once (an inverse that is exact to rounding keeps the multiply as accurate as a
+// backward-stable solve; formed in fp32 it costs a factor cond(L_kk): measured 18x larger
+// state error on the first, ill-conditioned update).
+// The 64x64x64 trailing products run on v_mfma_f32_32x32x2_f32.  LDS tiles are column-major
+// with a row stride of 65 floats: conflict-free for both operand orientations.
 #include "common.h"
 
 namespace {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 #define PB 64
-#define PLD 65  // LDS row stride: conflict-free for both row- and column-wise sweeps
+#define PLD 65  // LDS tile stride: element (r,c) of a tile lives at c*PLD + r  (column-major)
+#define ILD 17  // stride of a 16x16 inverse block in LDS
+#define INV_LDS (4 * 16 * ILD)
 
 __device__ inline float lane_bcast(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
+__device__ inline double lane_bcast_d(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
 
-// Factor the 64x64 block at S (lower triangle read) -> L (lower, upper zeroed) and
-// Linv = L^-1 (lower, ld 64).  One workgroup of 256 threads (4 wavefronts).
+// ---- tile movers (256 threads) ---------------------------------------------------------
+__device__ inline void load_tile(float* T, const float* __restrict__ G, int ld, int tid) {
+    // 64x64 column-major global tile -> LDS (c*PLD + r); 16-byte global loads along r
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int e = tid + it * 256;
+        const int c = e >> 4, r4 = (e & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(G + (size_t)c * ld + r4);
+        float* t = T + c * PLD + r4;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+}
+__device__ inline void store_tile(const float* T, float* __restrict__ G, int ld, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int e = tid + it * 256;
+        const int c = e >> 4, r4 = (e & 15) * 4;
+        const float* t = T + c * PLD + r4;
+        *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+// four 16x16 inverse blocks (global: block p at p*256, column-major ld 16) <-> LDS (stride ILD)
+__device__ inline void load_inv(float* Tinv, const float* __restrict__ G, int tid) {
+    const float4 v = *reinterpret_cast<const float4*>(G + tid * 4);
+    const int p = tid >> 6, c = (tid >> 2) & 15, r4 = (tid & 3) * 4;
+    float* t = Tinv + p * 16 * ILD + c * ILD + r4;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+}
+__device__ inline void store_inv(const float* Tinv, float* __restrict__ G, int tid) {
+    const int p = tid >> 6, c = (tid >> 2) & 15, r4 = (tid & 3) * 4;
+    const float* t = Tinv + p * 16 * ILD + c * ILD + r4;
+    *reinterpret_cast<float4*>(G + tid * 4) = make_float4(t[0], t[1], t[2], t[3]);
+}
+
+// acc(32x32 per wavefront) = sum_{q<64} A(i,q) * B(j,q);  A(i,q) at As[i*a_si + q*a_sq],
+// B(j,q) at Bs[j*b_sj + q*b_sq].  Operands are passed swapped so that the accumulator's
+// lane index runs along i:
+//   acc[reg] <-> (i = wr*32 + lane%32, j = wc*32 + (reg&3) + 8*(reg>>2) + 4*(lane/32)).
+__device__ inline f32x16 mma64(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int wr, int wc,
+                               int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+    const float* ap = As + (wr * 32 + li) * a_si + lk * a_sq;
+    const float* bp = Bs + (wc * 32 + li) * b_sj + lk * b_sq;
+#pragma unroll 8
+    for (int q = 0; q < PB; q += 2) {
+        const float a = ap[q * a_sq];
+        const float b = bp[q * b_sq];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// 16x16 tile: acc[reg] <-> (i = lane%16, j = 4*(lane/16) + reg);  acc = sum_{q<16} A(i,q)*B(j,q)
+__device__ inline f32x4 mma16(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4;
+    const float* ap = As + li * a_si + lk * a_sq;
+    const float* bp = Bs + li * b_sj + lk * b_sq;
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[q * b_sq], ap[q * a_sq], acc, 0, 0, 0);
+    return acc;
+}
+
+// X <- X L^-T for a 64x64 tile X (Tx) against the lower-triangular 64x64 block in Tl, given
+// the inverses of its four 16x16 diagonal blocks (Tinv).  Wavefront w owns rows 16w..16w+15;
+// no barrier inside.
+__device__ inline void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
+    const int r0 = 16 * wave, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        // Y_p(i,j) = sum_q X(r0+i, 16p+q) Inv_p(j,q)
+        const f32x4 y = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tinv + p * 16 * ILD, 1, ILD, lane);
+#pragma unroll
+        for (int g = 0; g < 4; g++) Tx[(16 * p + 4 * lk + g) * PLD + r0 + li] = y[g];
+#pragma unroll
+        for (int t = p + 1; t < 4; t++) {
+            // X(r0+i, 16t+j) -= sum_q Y_p(i,q) L(16t+j, 16p+q)
+            const f32x4 u = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tl + 16 * p * PLD + 16 * t, 1, PLD, lane);
+#pragma unroll
+            for (int g = 0; g < 4; g++) Tx[(16 * t + 4 * lk + g) * PLD + r0 + li] -= u[g];
+        }
+    }
+}
+// X <- X L^-1 (descending micro-blocks)
+__device__ inline void tri_solve_bwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
+    const int r0 = 16 * wave, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int p = 3; p >= 0; p--) {
+        // K_p(i,j) = sum_q X(r0+i, 16p+q) Inv_p(q,j)
+        const f32x4 y = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tinv + p * 16 * ILD, ILD, 1, lane);
+#pragma unroll
+        for (int g = 0; g < 4; g++) Tx[(16 * p + 4 * lk + g) * PLD + r0 + li] = y[g];
+#pragma unroll
+        for (int t = 0; t < p; t++) {
+            // X(r0+i, 16t+j) -= sum_q K_p(i,q) L(16p+q, 16t+j)
+            const f32x4 u = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tl + 16 * t * PLD + 16 * p, PLD, 1, lane);
+#pragma unroll
+            for (int g = 0; g < 4; g++) Tx[(16 * t + 4 * lk + g) * PLD + r0 + li] -= u[g];
+        }
+    }
+}
+
+// ---- 64x64 Cholesky inside one workgroup ------------------------------------------------
+// A: LDS tile holding (at least) the lower triangle of an SPD block; on return its lower
+// triangle is L and the strict upper triangle is zero.  Tinv receives the fp32-rounded
+// inverses of the four 16x16 diagonal blocks of L.  Returns true if a pivot was <= 0.
 //
-// Factorisation: four 16-column micro-panels.  Wavefront 0 holds one matrix row per lane
-// (16 panel entries in registers) and runs the 16 pivot steps with v_readlane broadcasts:
-// scaling the pivot column over all 64 lanes IS the panel's triangular solve, so no
-// barrier or LDS round trip sits on the pivot chain.  The 48x48 (then 32x32, 16x16)
-// trailing update is done by all four wavefronts from LDS.
-//
-// Inverse: formed in fp64 from the fp32 factor (16x16 diagonal blocks by substitution, one
-// per wavefront; off-diagonal blocks level by level) and rounded once to fp32.  An
-// inverse that is accurate to rounding makes "multiply by L_kk^-1" as good as a
-// backward-stable triangular solve (error eps*|Y||L||L^-1|); an inverse computed in fp32
-// would lose another factor cond(L_kk).
-__global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
-                                                      int ldl, float* __restrict__ Linv, int* info) {
-    __shared__ float A[PB * PLD];    // A[r*PLD + c]
-    __shared__ double Xd[PB * PLD];  // L^-1
-    __shared__ double Td[3 * 256];
-    __shared__ double Dinv[PB];
-    const int tid = threadIdx.x;
+// Four 16-column micro-panels.  Wavefront 0 holds one matrix row per lane (16 panel
+// entries in registers) and runs the 16 pivot steps with v_readlane broadcasts: scaling
+// the pivot column over all 64 lanes IS the panel's triangular solve, so no barrier or LDS
+// round trip sits on the pivot chain.  The trailing update runs on 16x16x4 MFMA tiles
+// spread over the four wavefronts.
+__device__ inline bool potrf64_lds(float* A, float* Tinv, int tid) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    for (int e = tid; e < PB * PB; e += 256) {
-        int r = e % PB, c = e / PB;
-        A[r * PLD + c] = (r >= c) ? S[(size_t)c * lds + r] : 0.f;
-        Xd[r * PLD + c] = 0.0;
-    }
-    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
     bool bad = false;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -55,7 +170,7 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
         if (wave == 0) {
             float a[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) a[j] = A[lane * PLD + c0 + j];
+            for (int j = 0; j < 16; j++) a[j] = A[(c0 + j) * PLD + lane];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 float d = lane_bcast(a[k], c0 + k);
@@ -63,8 +178,9 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
                     bad = true;
                     d = 1e-20f;
                 }
-                const float lkk = sqrtf(d);
-                const float inv = 1.0f / lkk;
+                float inv = __builtin_amdgcn_rsqf(d);
+                inv = inv * (1.5f - 0.5f * d * inv * inv);  // one Newton step: ~correctly rounded
+                const float lkk = d * inv;
                 a[k] = (lane == c0 + k) ? lkk : a[k] * inv;
 #pragma unroll
                 for (int j = k + 1; j < 16; j++) {
@@ -74,66 +190,184 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
             }
             if (lane >= c0) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) A[lane * PLD + c0 + j] = (lane - c0 >= j) ? a[j] : 0.f;
+                for (int j = 0; j < 16; j++) A[(c0 + j) * PLD + lane] = (lane - c0 >= j) ? a[j] : 0.f;
             }
         }
         __syncthreads();
-        const int r0 = c0 + 16;
-        const int rem = PB - r0;
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int r = r0 + e % rem, c = r0 + e / rem;
-            if (c <= r) {
-                float acc = A[r * PLD + c];
+        // trailing update on the 16x16 tiles (ti >= tj > p): A(r,s) -= sum_q P(r,q) P(s,q)
+        const int nt = 3 - p;               // tiles per side
+        const int ntile = nt * (nt + 1) / 2;
+        for (int t = wave; t < ntile; t += 4) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+            const int tj = t - ti * (ti + 1) / 2;
+            const int rb = c0 + 16 + 16 * ti, cb = c0 + 16 + 16 * tj;
+            const f32x4 u = mma16(A + c0 * PLD + rb, 1, PLD, A + c0 * PLD + cb, 1, PLD, lane);
 #pragma unroll
-                for (int j = 0; j < 16; j++) acc = __builtin_fmaf(-A[r * PLD + c0 + j], A[c * PLD + c0 + j], acc);
-                A[r * PLD + c] = acc;
-            }
+            for (int g = 0; g < 4; g++) A[(cb + 4 * lk + g) * PLD + rb + li] -= u[g];
         }
         __syncthreads();
     }
-    // ---- inverse in fp64 ----
-    if (tid < PB) Dinv[tid] = 1.0 / (double)A[tid * PLD + tid];
-    __syncthreads();
-    if (lane < 16) {
-        const int o = 16 * wave;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            double acc = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < r; q++) acc -= (double)A[(o + r) * PLD + o + q] * x[q];
-            x[r] = acc * Dinv[o + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) Xd[(o + r) * PLD + o + lane] = x[r];
-    }
-    __syncthreads();
-    for (int d = 1; d <= 3; d++) {
-        const int nblk = 4 - d;
-        for (int e = tid; e < 256 * nblk; e += 256) {
-            const int b = e >> 8, s = e & 15, c = (e >> 4) & 15;
-            const int j0 = 16 * b, i0 = 16 * (b + d);
-            double acc = 0.0;
-            for (int q = j0; q < i0; q++) acc += (double)A[(i0 + s) * PLD + q] * Xd[q * PLD + j0 + c];
-            Td[b * 256 + c * 16 + s] = acc;
-        }
-        __syncthreads();
-        for (int e = tid; e < 256 * nblk; e += 256) {
-            const int b = e >> 8, s = e & 15, c = (e >> 4) & 15;
-            const int j0 = 16 * b, i0 = 16 * (b + d);
-            double acc = 0.0;
-#pragma unroll
-            for (int t = 0; t < 16; t++) acc += Xd[(i0 + s) * PLD + i0 + t] * Td[b * 256 + c * 16 + t];
-            Xd[(i0 + s) * PLD + j0 + c] = -acc;
-        }
-        __syncthreads();
-    }
+    // zero the strict upper triangle (the tile may have carried the symmetric upper part)
     for (int e = tid; e < PB * PB; e += 256) {
-        int r = e % PB, c = e / PB;
-        L[(size_t)c * ldl + r] = A[r * PLD + c];
-        Linv[c * PB + r] = (float)Xd[r * PLD + c];
+        const int r = e % PB, c = e / PB;
+        if (r < c) A[c * PLD + r] = 0.f;
     }
+    // inverse of diagonal block `wave` in fp64: lane c < 16 owns column c of the inverse
+    {
+        const int o = 16 * wave;
+        const double dinv_own = 1.0 / (double)A[(o + li) * PLD + o + li];
+        double acc[16], x[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = (r == li) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double xq = acc[q] * lane_bcast_d(dinv_own, q);
+            x[q] = xq;
+#pragma unroll
+            for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fma(-(double)A[(o + q) * PLD + o + r], xq, acc[r]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) Tinv[wave * 16 * ILD + li * ILD + r] = (float)x[r];
+        }
+    }
+    __syncthreads();
+    return bad;
+}
+
+// Factor the first diagonal block (step "-1" of the sweep).
+__global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
+                                                      int ldl, float* __restrict__ Linv, int* info) {
+    __shared__ float A[PB * PLD];
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x;
+    load_tile(A, S, lds, tid);
+    __syncthreads();
+    const bool bad = potrf64_lds(A, Tinv, tid);
+    store_tile(A, L, ldl, tid);
+    store_inv(Tinv, Linv, tid);
     if (bad && tid == 0) atomicOr(info, 1);
+}
+
+// Block step k of the right-looking sweep; grid.x = r(r+1)/2 tiles, r = mb-1-k.
+__global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
+                                                        float* __restrict__ Linv, int k, int* info) {
+    __shared__ float Ti[PB * PLD];   // A_ik, then L_ik
+    __shared__ float Tj[PB * PLD];   // A_jk, then L_jk
+    __shared__ float Tl[PB * PLD];   // L_kk, later the updated next diagonal tile
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    // decode the lower-triangular tile index: t = ii(ii+1)/2 + jj, 0 <= jj <= ii
+    int t = blockIdx.x, ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+    const int jj = t - ii * (ii + 1) / 2;
+    const int i = k + 1 + ii, j = k + 1 + jj;
+
+    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
+    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
+    load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
+    if (i != j) load_tile(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
+    __syncthreads();
+    tri_solve_fwd(Ti, Tl, Tinv, wave, lane);             // L_ik = A_ik L_kk^-T
+    if (i != j) tri_solve_fwd(Tj, Tl, Tinv, wave, lane);  // L_jk
+    __syncthreads();
+    if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+    // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
+    const float* Bj = (i != j) ? Tj : Ti;
+    const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
+    float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
+    const int r = wr * 32 + (lane & 31);
+    if (i == k + 1 && j == k + 1) {
+        // next diagonal tile: update into LDS and factor it now (look-ahead)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            Tl[c * PLD + r] = Sij[(size_t)c * lds + r] - up[q];
+        }
+        __syncthreads();
+        const bool bad = potrf64_lds(Tl, Tinv, tid);
+        store_tile(Tl, L + (size_t)j * PB * ldl + (size_t)i * PB, ldl, tid);
+        store_inv(Tinv, Linv + (size_t)(k + 1) * PB * PB, tid);
+        if (bad && tid == 0) atomicOr(info, 1);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            Sij[(size_t)c * lds + r] -= up[q];
+        }
+    }
+}
+
+// Forward sweep step k of  Y L^T = X  (X: nrows x m_pad, ld ldx):  grid (slabs, mb-k).
+//   blockIdx.y == 0      : Y_k = X_k L_kk^-T                 -> W_k
+//   blockIdx.y == jj > 0 : X_j -= (X_k L_kk^-T) L_jk^T,  j = k + jj
+__global__ __launch_bounds__(256) void solve_fwd_kernel(float* __restrict__ X, float* __restrict__ W, int ldx,
+                                                        const float* __restrict__ L, int ldl,
+                                                        const float* __restrict__ Linv, int k) {
+    __shared__ float Tx[PB * PLD];
+    __shared__ float Tl[PB * PLD];
+    __shared__ float Tp[PB * PLD];
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int slab = blockIdx.x, jj = blockIdx.y, j = k + jj;
+    load_tile(Tx, X + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
+    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
+    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
+    if (jj > 0) load_tile(Tp, L + (size_t)k * PB * ldl + (size_t)j * PB, ldl, tid);
+    __syncthreads();
+    tri_solve_fwd(Tx, Tl, Tinv, wave, lane);
+    __syncthreads();
+    if (jj == 0) {
+        store_tile(Tx, W + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
+        return;
+    }
+    // X_j(r,s) -= sum_c Y(r,c) L_jk(s,c)
+    const f32x16 up = mma64(Tx, 1, PLD, Tp, 1, PLD, wr, wc, lane);
+    float* Xj = X + (size_t)j * PB * ldx + (size_t)slab * PB;
+    const int r = wr * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        Xj[(size_t)c * ldx + r] -= up[q];
+    }
+}
+
+// Backward sweep step k of  K L = Y  (Y in W, K written to X):  grid (slabs, k+1).
+//   blockIdx.y == 0      : K_k = W_k L_kk^-1                 -> X_k
+//   blockIdx.y == jj > 0 : W_j -= (W_k L_kk^-1) L_kj,  j = jj - 1
+__global__ __launch_bounds__(256) void solve_bwd_kernel(float* __restrict__ X, float* __restrict__ W, int ldx,
+                                                        const float* __restrict__ L, int ldl,
+                                                        const float* __restrict__ Linv, int k) {
+    __shared__ float Tx[PB * PLD];
+    __shared__ float Tl[PB * PLD];
+    __shared__ float Tp[PB * PLD];
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int slab = blockIdx.x, jj = blockIdx.y, j = jj - 1;
+    load_tile(Tx, W + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
+    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
+    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
+    if (jj > 0) load_tile(Tp, L + (size_t)j * PB * ldl + (size_t)k * PB, ldl, tid);
+    __syncthreads();
+    tri_solve_bwd(Tx, Tl, Tinv, wave, lane);
+    __syncthreads();
+    if (jj == 0) {
+        store_tile(Tx, X + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
+        return;
+    }
+    // W_j(r,s) -= sum_q K(r,q) L_kj(q,s):  B(j=s,q) = L_kj(q,s) at s*PLD + q
+    const f32x16 up = mma64(Tx, 1, PLD, Tp, PLD, 1, wr, wc, lane);
+    float* Wj = W + (size_t)j * PB * ldx + (size_t)slab * PB;
+    const int r = wr * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        Wj[(size_t)c * ldx + r] -= up[q];
+    }
 }
 
 }  // namespace
@@ -141,51 +375,22 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
 void launch_cholesky(ekfvio_filter* f, float* S, float* L, float* Linv, int m_pad, int lds) {
     ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0);
     const int mb = m_pad / PB;
-    for (int k = 0; k < mb; k++) {
-        float* Skk = S + (size_t)k * PB * lds + k * PB;
-        float* Lkk = L + (size_t)k * PB * lds + k * PB;
-        float* Li = Linv + (size_t)k * PB * PB;
-        hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Skk, lds, Lkk, lds, Li, f->info);
-        const int rem = m_pad - (k + 1) * PB;
-        if (rem > 0) {
-            float* Spanel = Skk + PB;  // rows below the diagonal block, same columns
-            float* Lpanel = Lkk + PB;
-            float* S22 = S + (size_t)(k + 1) * PB * lds + (k + 1) * PB;
-            // L_ik = S_ik * Linv_kk^T
-            launch_gemm(f->stream, 1, rem, PB, PB, 1.f, Spanel, lds, Li, PB, 0.f, nullptr, 0, Lpanel, lds, 0);
-            // S_22 -= L_21 * L_21^T
-            launch_gemm(f->stream, 1, rem, rem, PB, -1.f, Lpanel, lds, Lpanel, lds, 1.f, S22, lds, S22, lds, 0);
-        }
+    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, S, lds, L, lds, Linv, f->info);
+    for (int k = 0; k + 1 < mb; k++) {
+        const int r = mb - 1 - k;
+        hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2), dim3(256), 0, f->stream, S, lds, L, lds, Linv, k,
+                           f->info);
     }
 }
 
-// X <- X * S^-1 with S = L L^T; X is nrows x m_pad (ld = ldx), W scratch of the same shape.
+// X <- X * A^-1 with A = L L^T; X is nrows x m_pad (ld = ldx, rows padded to 64), W scratch.
 void launch_solve_right(ekfvio_filter* f, const float* L, const float* Linv, int m_pad, int lds, float* X, float* W,
                         int nrows, int ldx) {
     ProfScope ps(f, PC_SOLVE, 2.0 * nrows * (double)m_pad * m_pad);
     const int mb = m_pad / PB;
-    // forward: Y L^T = X   ->  W holds Y
-    for (int k = 0; k < mb; k++) {
-        const float* Li = Linv + (size_t)k * PB * PB;
-        float* Xk = X + (size_t)k * PB * ldx;
-        float* Wk = W + (size_t)k * PB * ldx;
-        launch_gemm(f->stream, 1, nrows, PB, PB, 1.f, Xk, ldx, Li, PB, 0.f, nullptr, 0, Wk, ldx, 0);
-        const int rem = m_pad - (k + 1) * PB;
-        if (rem > 0) {
-            const float* Lpanel = L + (size_t)k * PB * lds + (k + 1) * PB;  // [rem x 64]
-            float* Xr = X + (size_t)(k + 1) * PB * ldx;
-            launch_gemm(f->stream, 1, nrows, rem, PB, -1.f, Wk, ldx, Lpanel, lds, 1.f, Xr, ldx, Xr, ldx, 0);
-        }
-    }
-    // backward: K L = Y   ->  X holds K
-    for (int k = mb - 1; k >= 0; k--) {
-        const float* Li = Linv + (size_t)k * PB * PB;
-        float* Xk = X + (size_t)k * PB * ldx;
-        const float* Wk = W + (size_t)k * PB * ldx;
-        launch_gemm(f->stream, 0, nrows, PB, PB, 1.f, Wk, ldx, Li, PB, 0.f, nullptr, 0, Xk, ldx, 0);
-        if (k > 0) {
-            const float* Lrow = L + (size_t)k * PB;  // block row k, columns 0..k*64: [64 x k*64]
-            launch_gemm(f->stream, 0, nrows, k * PB, PB, -1.f, Xk, ldx, Lrow, lds, 1.f, W, ldx, W, ldx, 0);
-        }
-    }
+    const int slabs = (nrows + PB - 1) / PB;
+    for (int k = 0; k < mb; k++)
+        hipLaunchKernelGGL(solve_fwd_kernel, dim3(slabs, mb - k), dim3(256), 0, f->stream, X, W, ldx, L, lds, Linv, k);
+    for (int k = mb - 1; k >= 0; k--)
+        hipLaunchKernelGGL(solve_bwd_kernel, dim3(slabs, k + 1), dim3(256), 0, f->stream, X, W, ldx, L, lds, Linv, k);
 }

@@ -437,26 +437,35 @@ __global__ __launch_bounds__(256) void form_G_kernel(const float* __restrict__ K
     G[(size_t)r * ld + i] = g;
 }
 
-// mu += K*y (:600), quaternion renormalisation (:605-609).  One thread per state row.
+// mu += K*y (:600), quaternion renormalisation (:605-609).  64 state rows per workgroup;
+// the four wavefronts each sum a quarter of the measurement rows (coalesced along the state
+// index), combined in ascending order.
 __global__ __launch_bounds__(256) void mean_update_kernel(const float* __restrict__ K, int ld, int n, int m,
                                                           const float* __restrict__ y, float* mu) {
+    __shared__ float s_part[4][64];
     __shared__ float s_q[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float v = 0.f;
+    const int rl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + rl;
+    const int chunk = (m + 3) / 4;
+    const int r0 = w * chunk, r1 = min(m, r0 + chunk);
+    float acc = 0.f;
     if (i < n) {
-        float acc = 0.f;
-        for (int r = 0; r < m; r++) acc = acc + K[(size_t)r * ld + i] * y[r];
-        v = mu[i] + acc;
+#pragma unroll 8
+        for (int r = r0; r < r1; r++) acc = acc + K[(size_t)r * ld + i] * y[r];
     }
+    s_part[w][rl] = acc;
+    __syncthreads();
+    float v = 0.f;
+    if (w == 0 && i < n) v = mu[i] + (((s_part[0][rl] + s_part[1][rl]) + s_part[2][rl]) + s_part[3][rl]);
     if (blockIdx.x == 0) {
-        if (threadIdx.x >= 3 && threadIdx.x <= 6) s_q[threadIdx.x - 3] = v;
+        if (w == 0 && rl >= 3 && rl <= 6) s_q[rl - 3] = v;
         __syncthreads();
-        if (threadIdx.x >= 3 && threadIdx.x <= 6) {
+        if (w == 0 && rl >= 3 && rl <= 6) {
             float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
             v = v / qn;
         }
     }
-    if (i < n) mu[i] = v;
+    if (w == 0 && i < n) mu[i] = v;
 }
 
 __global__ void check_sigma_kernel(const float* P, int ld, int n, float* out) {
@@ -569,7 +578,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     }
     {
         ProfScope ps(f, PC_UPDATE_MISC);
-        hipLaunchKernelGGL(mean_update_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, f->Km, ld, n, m, f->yres,
+        hipLaunchKernelGGL(mean_update_kernel, dim3((n + 63) / 64), dim3(256), 0, f->stream, f->Km, ld, n, m, f->yres,
                            f->mu);
     }
 }

@@ -188,8 +188,8 @@ class TightlyCoupledEKF:
         B = np.asarray(B, np.float32)
         M, K = A.shape
         N = B.shape[0] if transB else B.shape[1]
-        Ac, Bc = np.ascontiguousarray(A.T), np.ascontiguousarray(B.T)  # column-major buffers
-        Cc = np.ascontiguousarray(np.asarray(C0, np.float32).T)
+        Ac, Bc = np.array(A.T, order="C", copy=True), np.array(B.T, order="C", copy=True)  # column-major buffers
+        Cc = np.array(np.asarray(C0, np.float32).T, order="C", copy=True)  # never alias the caller's C0
         self._chk(self.lib.ekfvio_test_gemm(self.h, int(transB), M, N, K, alpha, _fp(Ac), M, _fp(Bc), B.shape[0], beta,
                                             _fp(Cc), M))
         return Cc.T.copy()
@@ -199,7 +199,7 @@ class TightlyCoupledEKF:
         S = np.asarray(S, np.float32)
         Crhs = np.asarray(Crhs, np.float32)
         m, nr = S.shape[0], Crhs.shape[0]
-        Sc, Cc = np.ascontiguousarray(S.T), np.ascontiguousarray(Crhs.T)
+        Sc, Cc = np.array(S.T, order="C", copy=True), np.array(Crhs.T, order="C", copy=True)
         L = np.zeros((m, m), np.float32)
         X = np.zeros((m, nr), np.float32)
         info = C.c_int32(0)
