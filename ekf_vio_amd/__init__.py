@@ -5,4 +5,4 @@ filter.py (host mirror of the reference's TightlyCoupledEKF interface), sim.py (
 synthetic scenario generator).  There is no CPU compute path in this package.
 """
 from .capi import EkfvioError, load  # noqa: F401
-from .filter import TightlyCoupledEKF  # noqa: F401
+from .filter import EKFVIO, KLTTracker, TightlyCoupledEKF  # noqa: F401

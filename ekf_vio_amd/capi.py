@@ -31,7 +31,8 @@ SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_r
            "ekfvio_add_features", "ekfvio_process", "ekfvio_linearize", "ekfvio_update", "ekfvio_measurement_map",
            "ekfvio_num_features", "ekfvio_dim", "ekfvio_get_base_mu", "ekfvio_get_features", "ekfvio_get_sigma",
            "ekfvio_get_feature_cov", "ekfvio_get_depth_variance", "ekfvio_check_sigma", "ekfvio_set_state",
-           "ekfvio_klt_push_frame", "ekfvio_klt_track", "ekfvio_klt_track_points", "ekfvio_step_image", "ekfvio_imu",
+           "ekfvio_klt_push_frame", "ekfvio_klt_track", "ekfvio_klt_track_points", "ekfvio_klt_get_level",
+           "ekfvio_step_image", "ekfvio_imu",
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
            "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
            "ekfvio_test_gemm", "ekfvio_test_cholesky_solve"]
@@ -67,6 +68,7 @@ def load(build_if_missing=True):
         "ekfvio_check_sigma": [vp, fp, fp], "ekfvio_set_state": [vp, i32, fp, fp, fp, u8p, fp, i32],
         "ekfvio_klt_push_frame": [vp, u8p, i32, i32, i32, fp], "ekfvio_klt_track": [vp, fp, fp, u8p],
         "ekfvio_klt_track_points": [vp, fp, fp, i32, fp, u8p],
+        "ekfvio_klt_get_level": [vp, i32, ip, ip, u8p, C.POINTER(C.c_int16)],
         "ekfvio_step_image": [vp, C.c_double, u8p, i32, i32, i32, fp], "ekfvio_imu": [vp, C.c_double, fp, fp],
         "ekfvio_upload_measurements": [vp, i32, fp, fp, u8p], "ekfvio_run_uploaded": [vp, i32, i32, f32],
         "ekfvio_synchronize": [vp], "ekfvio_profile_enable": [vp, i32], "ekfvio_profile_reset": [vp],

@@ -1,25 +1,548 @@
-// ekf_vio_amd/csrc/klt.hip — pyramidal Lucas-Kanade tracker (placeholder until the HIP
-// tracker lands; the entry points fail loudly rather than fall back to anything).
+// ekf_vio_amd/csrc/klt.hip — pyramidal Lucas-Kanade tracker on the GPU.
+//
+// Replaces KLTTracker::findNewFeaturePositions (include/ekf_vio/KLTTracker.cpp:29-95), i.e.
+// cv::calcOpticalFlowPyrLK(lf.img, cf.img, prev, init, Size(21,21), maxLevel 3,
+// {COUNT+EPS, 30, 0.01}, OPTFLOW_USE_INITIAL_FLOW, minEig 1e-4) plus the pass / metric
+// conversion loop around it (:72-92).  The arithmetic restates OpenCV 3.x's published
+// algorithm (see oracle/klt_oracle.cpp for the itemised list); the gradient matrix and the
+// mismatch vector are accumulated in exact 64-bit integers, which makes the result
+// independent of the reduction order.
+//
+// Data layout in HBM, per frame and pyramid level: the 8-bit image with a border of
+// KLT_BORDER pixels on every side, filled by reflect-101 (what OpenCV's pyramid border
+// holds), rows padded to 64 B; and the int16 (dx,dy) Scharr derivatives with the same
+// geometry and a ZERO border.  With the borders materialised the tracker's inner loops are
+// branch-free: every window that passes OpenCV's bounds test lies inside the padded level.
+//
+// Kernels: klt_pad_kernel (upload -> padded level 0), klt_pyrdown_kernel (5x5 binomial,
+// integer, one thread per padded output pixel, coalesced row reads), klt_scharr_kernel,
+// and klt_track_kernel: one wavefront per landmark, all pyramid levels inside the kernel;
+// the 21x21 window is spread over the 64 lanes (7 pixels per lane, template patch and
+// gradients in registers), the search region of the current frame is staged in LDS once
+// per level (re-staged only if the window walks out of it), and the per-iteration sums are
+// 64-bit wave reductions.
+#include <math.h>
+
 #include "common.h"
 
-int klt_alloc(ekfvio_filter*) { return EKFVIO_OK; }
-void klt_free(ekfvio_filter*) {}
+#define KLT_BORDER 24     // >= window size (21); multiple of 8
+#define KLT_MAX_WIN 21
+#define KLT_SLOTS 7       // ceil(21*21/64)
+#define KLT_R 8           // staging margin around the window
+#define KLT_RS (KLT_MAX_WIN + 1 + 2 * KLT_R)  // staged region edge (38)
+#define KLT_RP 40         // LDS row pitch of the staged region
+
+#define HIPK(f, expr)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            (f)->last_error = std::string(#expr) + ": " + hipGetErrorString(e__);  \
+            return EKFVIO_EDEVICE;                                                 \
+        }                                                                          \
+    } while (0)
+
+namespace {
+
+struct LevelView {
+    const uint8_t* img;  // points at padded (0,0)
+    const short* der;    // interleaved dx,dy; padded (0,0)
+    int w, h, pitch;     // pitch in pixels (same for img bytes and der short2)
+};
+struct PyrView {
+    LevelView lv[4];
+    int levels;
+};
+
+__device__ __host__ inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+__global__ void klt_pad_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, uint8_t* dst, int pitch) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    if (X >= w + 2 * KLT_BORDER) return;
+    const int x = reflect101(X - KLT_BORDER, w), y = reflect101(Y - KLT_BORDER, h);
+    dst[(size_t)Y * pitch + X] = src[(size_t)y * stride + x];
+}
+
+// pyrDown: [1 4 6 4 1]^2 / 256 with (v + 128) >> 8, BORDER_REFLECT_101 (the source border)
+__global__ void klt_pyrdown_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch, uint8_t* dst, int dw,
+                                   int dh, int dpitch) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    if (X >= dw + 2 * KLT_BORDER) return;
+    const int x = reflect101(X - KLT_BORDER, dw), y = reflect101(Y - KLT_BORDER, dh);
+    const uint8_t* s = src + (size_t)(2 * y + KLT_BORDER) * spitch + 2 * x + KLT_BORDER;
+    int v = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; j++) {
+        const uint8_t* r = s + j * spitch;
+        const int rs = r[-2] + r[2] + 4 * (r[-1] + r[1]) + 6 * r[0];
+        const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+        v += wj * rs;
+    }
+    dst[(size_t)Y * dpitch + X] = (uint8_t)((v + 128) >> 8);
+    (void)sw;
+    (void)sh;
+}
+
+// Scharr derivatives of the level interior; the derivative border stays zero.
+__global__ void klt_scharr_kernel(const uint8_t* __restrict__ img, int w, int h, int pitch, short* der) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* c = img + (size_t)(y + KLT_BORDER) * pitch + x + KLT_BORDER;
+    const uint8_t *u = c - pitch, *d = c + pitch;
+    const int t0m = (u[-1] + d[-1]) * 3 + c[-1] * 10, t0p = (u[1] + d[1]) * 3 + c[1] * 10;
+    const int t1m = d[-1] - u[-1], t1c = d[0] - u[0], t1p = d[1] - u[1];
+    short* o = der + ((size_t)(y + KLT_BORDER) * pitch + x + KLT_BORDER) * 2;
+    o[0] = (short)(t0p - t0m);
+    o[1] = (short)((t1p + t1m) * 3 + t1c * 10);
+}
+
+__device__ inline long long wave_sum(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// One wavefront per point.  Mirrors LKTrackerInvoker; every scalar expression is evaluated
+// redundantly (and identically) by all 64 lanes.
+__global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, const float* __restrict__ prev_px,
+                                                       float* next_px, uint8_t* status, int n, int win, int max_iter,
+                                                       float eps2, float min_eig) {
+    __shared__ uint8_t reg[KLT_RS * KLT_RP];
+    const int pt = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (pt >= n) return;
+    const int levels = min(P.levels, Q.levels);
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float half = (win - 1) * 0.5f;
+    const int npix = win * win;
+    // slot geometry: pixel s = lane + 64*t  ->  (x, y) inside the window
+    int sx[KLT_SLOTS], sy[KLT_SLOTS];
+    bool sv[KLT_SLOTS];
+#pragma unroll
+    for (int t = 0; t < KLT_SLOTS; t++) {
+        const int s = lane + 64 * t;
+        sv[t] = s < npix;
+        sx[t] = sv[t] ? s % win : 0;
+        sy[t] = sv[t] ? s / win : 0;
+    }
+    const float ppx0 = prev_px[2 * pt], ppy0 = prev_px[2 * pt + 1];
+    float ox = next_px[2 * pt], oy = next_px[2 * pt + 1];
+    bool ok = true;
+    for (int level = levels - 1; level >= 0; level--) {
+        const LevelView I = P.lv[level];
+        const LevelView J = Q.lv[level];
+        const float sc = (float)(1. / (1 << level));
+        float ppx = ppx0 * sc, ppy = ppy0 * sc;
+        if (level == levels - 1) {
+            ox = ox * sc;
+            oy = oy * sc;
+        } else {
+            ox = ox * 2.f;
+            oy = oy * 2.f;
+        }
+        ppx -= half;
+        ppy -= half;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -win || ipx >= I.w || ipy < -win || ipy >= I.h) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        float a = ppx - ipx, b = ppy - ipy;
+        int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << W_BITS));
+        int iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
+        int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        int Iv[KLT_SLOTS], Ix[KLT_SLOTS], Iy[KLT_SLOTS];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int t = 0; t < KLT_SLOTS; t++) {
+            Iv[t] = Ix[t] = Iy[t] = 0;
+            if (sv[t]) {
+                const size_t o = (size_t)(ipy + sy[t] + KLT_BORDER) * I.pitch + (ipx + sx[t] + KLT_BORDER);
+                const uint8_t* ip = I.img + o;
+                const short* dp = I.der + o * 2;
+                Iv[t] = descale(ip[0] * iw00 + ip[1] * iw01 + ip[I.pitch] * iw10 + ip[I.pitch + 1] * iw11, W_BITS - 5);
+                const int dpn = I.pitch * 2;
+                Ix[t] = descale(dp[0] * iw00 + dp[2] * iw01 + dp[dpn] * iw10 + dp[dpn + 2] * iw11, W_BITS);
+                Iy[t] = descale(dp[1] * iw00 + dp[3] * iw01 + dp[dpn + 1] * iw10 + dp[dpn + 3] * iw11, W_BITS);
+                sA11 += (long long)Ix[t] * Ix[t];
+                sA12 += (long long)Ix[t] * Iy[t];
+                sA22 += (long long)Iy[t] * Iy[t];
+            }
+        }
+        sA11 = wave_sum(sA11);
+        sA12 = wave_sum(sA12);
+        sA22 = wave_sum(sA22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < min_eig || D < 1.1920929e-07f) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        D = 1.f / D;
+        float nx = ox - half, ny = oy - half;
+        float pdx = 0.f, pdy = 0.f;
+        int rx0 = 0, ry0 = 0;
+        bool staged = false;
+        for (int j = 0; j < max_iter; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
+                if (level == 0) ok = false;
+                break;
+            }
+            if (!staged || inx < rx0 || iny < ry0 || inx + win > rx0 + KLT_RS - 1 || iny + win > ry0 + KLT_RS - 1) {
+                // (re)stage the search region [rx0, rx0+RS) x [ry0, ry0+RS) of J into LDS, clamped to the padded level
+                rx0 = min(max(inx - KLT_R, -KLT_BORDER), J.w + KLT_BORDER - KLT_RS);
+                ry0 = min(max(iny - KLT_R, -KLT_BORDER), J.h + KLT_BORDER - KLT_RS);
+                __syncthreads();
+                for (int e = lane; e < KLT_RS * KLT_RS; e += 64) {
+                    const int ry = e / KLT_RS, rx = e % KLT_RS;
+                    reg[ry * KLT_RP + rx] = J.img[(size_t)(ry0 + ry + KLT_BORDER) * J.pitch + rx0 + rx + KLT_BORDER];
+                }
+                __syncthreads();
+                staged = true;
+            }
+            a = nx - inx;
+            b = ny - iny;
+            iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
+            iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            long long sb1 = 0, sb2 = 0;
+            const int bx = inx - rx0, by = iny - ry0;
+#pragma unroll
+            for (int t = 0; t < KLT_SLOTS; t++) {
+                if (sv[t]) {
+                    const uint8_t* jp = reg + (by + sy[t]) * KLT_RP + bx + sx[t];
+                    const int diff =
+                        descale(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_RP] * iw10 + jp[KLT_RP + 1] * iw11, W_BITS - 5) - Iv[t];
+                    sb1 += (long long)diff * Ix[t];
+                    sb2 += (long long)diff * Iy[t];
+                }
+            }
+            sb1 = wave_sum(sb1);
+            sb2 = wave_sum(sb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx;
+            ny += dy;
+            ox = nx + half;
+            oy = ny + half;
+            if (dx * dx + dy * dy <= eps2) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                ox -= dx * 0.5f;
+                oy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+        if (ok && level == 0) {
+            const int fx = (int)floorf(ox - half), fy = (int)floorf(oy - half);
+            if (fx < -win || fx >= J.w || fy < -win || fy >= J.h) ok = false;
+        }
+    }
+    if (lane == 0) {
+        next_px[2 * pt] = ox;
+        next_px[2 * pt + 1] = oy;
+        status[pt] = ok ? 1 : 0;
+    }
+}
+
+// KLTTracker.cpp:53-59: reference pixels from the last KLT result (previous frame's K),
+// initial guesses from the EKF-predicted landmark positions (current frame's K).
+// Feature.h:60-66 indexes the column-major 3x3 K linearly, so K(2) and K(5) are the zero
+// entries K[2,0], K[2,1]: the principal point is ignored unless use_pp is set.
+__global__ void klt_points_kernel(const float* __restrict__ last_klt, const float* __restrict__ mu, int N, float fxp,
+                                  float fyp, float cxp, float cyp, float fxc, float fyc, float cxc, float cyc,
+                                  float* prev_px, float* next_px) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    prev_px[2 * i] = last_klt[2 * i] * fxp + cxp;
+    prev_px[2 * i + 1] = last_klt[2 * i + 1] * fyp + cyp;
+    next_px[2 * i] = fxc * mu[EKF_BASE + 3 * i] + cxc;
+    next_px[2 * i + 1] = fyc * mu[EKF_BASE + 3 * i + 1] + cyc;
+}
+
+// KLTTracker.cpp:72-92: pass = status && inside the kill pad; z = pixel2Metric; R = 1e-5 I px^2
+// scaled by (1/fx)^2 on row 0 and (1/fy)^2 on row 1.
+__global__ void klt_finish_kernel(const float* __restrict__ next_px, const uint8_t* __restrict__ status, int N, int w,
+                                  int h, int kill_pad, float fx, float fy, float cx, float cy, float r0, float r1, float* z,
+                                  float* R, uint8_t* pass) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float x = next_px[2 * i], y = next_px[2 * i + 1];
+    const bool p = status[i] == 1 && !(x < kill_pad || y < kill_pad || w - x < kill_pad || h - y < kill_pad);
+    pass[i] = p ? 1 : 0;
+    if (p) {
+        z[2 * i] = (x - cx) / fx;
+        z[2 * i + 1] = (y - cy) / fy;
+        R[4 * i] = r0;
+        R[4 * i + 1] = 0.f;  // the off-diagonals of estimateUncertainty are zero, scaled or not
+        R[4 * i + 2] = 0.f;
+        R[4 * i + 3] = r1;
+    } else {
+        z[2 * i] = 0.f;
+        z[2 * i + 1] = 0.f;
+        R[4 * i] = R[4 * i + 1] = R[4 * i + 2] = R[4 * i + 3] = 0.f;
+    }
+}
+
+int level_pitch(int w) { return round_up(w + 2 * KLT_BORDER, 64); }
+
+PyrView make_view(const KltFrame& fr) {
+    PyrView v;
+    v.levels = fr.levels;
+    for (int l = 0; l < 4; l++) {
+        v.lv[l].img = fr.img[l];
+        v.lv[l].der = fr.deriv[l];
+        v.lv[l].w = fr.w[l];
+        v.lv[l].h = fr.h[l];
+        v.lv[l].pitch = (l < fr.levels) ? level_pitch(fr.w[l]) : 0;
+    }
+    return v;
+}
+
+}  // namespace
+
+int klt_alloc(ekfvio_filter* f) {
+    const ekfvio_config& c = f->cfg;
+    if (c.klt_window_size < 3 || c.klt_window_size > KLT_MAX_WIN || (c.klt_window_size & 1) == 0 ||
+        c.klt_max_pyramid_level < 0 || c.klt_max_pyramid_level > 3 || c.max_image_width < 1 || c.max_image_height < 1) {
+        f->last_error = "KLT config: odd window <= 21 and max level <= 3 are supported";
+        return EKFVIO_EINVAL;
+    }
+    for (int fr = 0; fr < 2; fr++) {
+        int w = c.max_image_width, h = c.max_image_height;
+        for (int l = 0; l <= c.klt_max_pyramid_level; l++) {
+            const size_t px = (size_t)level_pitch(w) * (h + 2 * KLT_BORDER);
+            HIPK(f, hipMalloc((void**)&f->frames[fr].img[l], px));
+            HIPK(f, hipMalloc((void**)&f->frames[fr].deriv[l], px * 2 * sizeof(short)));
+            HIPK(f, hipMemsetAsync(f->frames[fr].img[l], 0, px, f->stream));
+            HIPK(f, hipMemsetAsync(f->frames[fr].deriv[l], 0, px * 2 * sizeof(short), f->stream));
+            w = (w + 1) / 2;
+            h = (h + 1) / 2;
+        }
+    }
+    const size_t maxf = f->cfg.max_features > 0 ? f->cfg.max_features : 1;
+    HIPK(f, hipMalloc((void**)&f->klt_prev_px, sizeof(float) * 2 * maxf));
+    HIPK(f, hipMalloc((void**)&f->klt_next_px, sizeof(float) * 2 * maxf));
+    HIPK(f, hipMalloc((void**)&f->klt_status, maxf));
+    HIPK(f, hipMalloc((void**)&f->staging, (size_t)c.max_image_width * c.max_image_height));
+    return EKFVIO_OK;
+}
+
+void klt_free(ekfvio_filter* f) {
+    for (int fr = 0; fr < 2; fr++)
+        for (int l = 0; l < 8; l++) {
+            if (f->frames[fr].img[l]) (void)hipFree(f->frames[fr].img[l]);
+            if (f->frames[fr].deriv[l]) (void)hipFree(f->frames[fr].deriv[l]);
+        }
+    if (f->klt_prev_px) (void)hipFree(f->klt_prev_px);
+    if (f->klt_next_px) (void)hipFree(f->klt_next_px);
+    if (f->klt_status) (void)hipFree(f->klt_status);
+    if (f->staging) (void)hipFree(f->staging);
+}
+
+// Device-side part of klt_push_frame: staging -> pyramid + derivatives of frames[cur]
+static int build_pyramid(ekfvio_filter* f, KltFrame& fr, int w, int h) {
+    const int win = f->cfg.klt_window_size;
+    fr.w[0] = w;
+    fr.h[0] = h;
+    fr.levels = 1;
+    for (int l = 1; l <= f->cfg.klt_max_pyramid_level; l++) {
+        const int lw = (fr.w[l - 1] + 1) / 2, lh = (fr.h[l - 1] + 1) / 2;
+        if (lw <= win || lh <= win) break;  // buildOpticalFlowPyramid: level not larger than the window
+        fr.w[l] = lw;
+        fr.h[l] = lh;
+        fr.levels = l + 1;
+    }
+    ProfScope ps(f, PC_KLT_PYRAMID);
+    {
+        const int pw = w + 2 * KLT_BORDER, ph = h + 2 * KLT_BORDER;
+        hipLaunchKernelGGL(klt_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, f->stream, f->staging, w, h, w,
+                           fr.img[0], level_pitch(w));
+    }
+    for (int l = 1; l < fr.levels; l++) {
+        const int pw = fr.w[l] + 2 * KLT_BORDER, ph = fr.h[l] + 2 * KLT_BORDER;
+        hipLaunchKernelGGL(klt_pyrdown_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, f->stream, fr.img[l - 1],
+                           fr.w[l - 1], fr.h[l - 1], level_pitch(fr.w[l - 1]), fr.img[l], fr.w[l], fr.h[l],
+                           level_pitch(fr.w[l]));
+    }
+    for (int l = 0; l < fr.levels; l++)
+        hipLaunchKernelGGL(klt_scharr_kernel, dim3((fr.w[l] + 255) / 256, fr.h[l]), dim3(256), 0, f->stream, fr.img[l],
+                           fr.w[l], fr.h[l], level_pitch(fr.w[l]), fr.deriv[l]);
+    return EKFVIO_OK;
+}
+
+static void intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy) {
+    // CameraInfo.K is row-major [fx 0 cx; 0 fy cy; 0 0 1].  Feature.h:60-66 reads K(0), K(4)
+    // and, for the offsets, K(2) and K(5) of a column-major Matrix3f = the zero entries K[2,0]
+    // and K[2,1]: the principal point is ignored by the reference (self-consistently).
+    *fx = K[0];
+    *fy = K[4];
+    *cx = f->cfg.use_principal_point ? K[2] : 0.f;
+    *cy = f->cfg.use_principal_point ? K[5] : 0.f;
+}
+
+static int track_points_device(ekfvio_filter* f, int n) {
+    const KltFrame& prev = f->frames[f->cur ^ 1];
+    const KltFrame& cur = f->frames[f->cur];
+    const float eps = f->cfg.klt_epsilon;
+    ProfScope ps(f, PC_KLT_TRACK);
+    hipLaunchKernelGGL(klt_track_kernel, dim3(n), dim3(64), 0, f->stream, make_view(prev), make_view(cur), f->klt_prev_px,
+                       f->klt_next_px, f->klt_status, n, f->cfg.klt_window_size, f->cfg.klt_max_iterations, eps * eps,
+                       f->cfg.klt_min_eigen);
+    return EKFVIO_OK;
+}
+
+// Runs the tracker for the current landmarks; results land in f->zmeas / Rmeas / pass (device).
+int klt_track_device(ekfvio_filter* f) {
+    const KltFrame& prev = f->frames[f->cur ^ 1];
+    const KltFrame& cur = f->frames[f->cur];
+    if (!prev.valid || !cur.valid) {
+        f->last_error = "KLT needs two frames";
+        return EKFVIO_ESTATE;
+    }
+    const int N = f->N;
+    if (N == 0) return EKFVIO_OK;
+    float fxp, fyp, cxp, cyp, fxc, fyc, cxc, cyc;
+    intrinsics(f, prev.K, &fxp, &fyp, &cxp, &cyp);
+    intrinsics(f, cur.K, &fxc, &fyc, &cxc, &cyc);
+    hipLaunchKernelGGL(klt_points_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->last_klt, f->mu, N, fxp, fyp,
+                       cxp, cyp, fxc, fyc, cxc, cyc, f->klt_prev_px, f->klt_next_px);
+    track_points_device(f, N);
+    // estimateUncertainty (:100-106) = 1e-5 I; scale = pow(1.0/K(0,0), 2) in double, narrowed
+    const float r0 = 0.00001f * (float)pow(1.0 / (double)cur.K[0], 2);
+    const float r1 = 0.00001f * (float)pow(1.0 / (double)cur.K[4], 2);
+    hipLaunchKernelGGL(klt_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->klt_next_px, f->klt_status, N,
+                       cur.w[0], cur.h[0], f->cfg.kill_pad, fxc, fyc, cxc, cyc, r0, r1, f->zmeas, f->Rmeas, f->pass);
+    return EKFVIO_OK;
+}
 
 extern "C" {
-int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t*, int32_t, int32_t, int32_t, const float*) {
-    if (f) f->last_error = "KLT not built";
-    return EKFVIO_ESTATE;
+
+int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                          const float K[9]) {
+    if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
+    if (width > f->cfg.max_image_width || height > f->cfg.max_image_height) return EKFVIO_ECAPACITY;
+    HIPK(f, hipSetDevice(f->device));
+    HIPK(f, hipMemcpy2DAsync(f->staging, width, image, stride, width, height, hipMemcpyHostToDevice, f->stream));
+    f->cur ^= 1;  // the former current frame becomes the previous one (frame_buffer depth 2)
+    KltFrame& fr = f->frames[f->cur];
+    for (int i = 0; i < 9; i++) fr.K[i] = K[i];
+    build_pyramid(f, fr, width, height);
+    fr.valid = true;
+    HIPK(f, hipGetLastError());
+    HIPK(f, hipStreamSynchronize(f->stream));  // the caller's image buffer may be reused
+    return EKFVIO_OK;
 }
-int ekfvio_klt_track(ekfvio_filter* f, float*, float*, uint8_t*) {
-    if (f) f->last_error = "KLT not built";
-    return EKFVIO_ESTATE;
+
+int ekfvio_klt_track(ekfvio_filter* f, float* z2N, float* R4N, uint8_t* passN) {
+    if (!f) return EKFVIO_EINVAL;
+    HIPK(f, hipSetDevice(f->device));
+    int rc = klt_track_device(f);
+    if (rc != EKFVIO_OK) return rc;
+    const int N = f->N;
+    if (N > 0) {
+        if (z2N) HIPK(f, hipMemcpyAsync(z2N, f->zmeas, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, f->stream));
+        if (R4N) HIPK(f, hipMemcpyAsync(R4N, f->Rmeas, sizeof(float) * 4 * N, hipMemcpyDeviceToHost, f->stream));
+        if (passN) HIPK(f, hipMemcpyAsync(passN, f->pass, N, hipMemcpyDeviceToHost, f->stream));
+    }
+    HIPK(f, hipGetLastError());
+    HIPK(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
 }
-int ekfvio_klt_track_points(ekfvio_filter* f, const float*, const float*, int32_t, float*, uint8_t*) {
-    if (f) f->last_error = "KLT not built";
-    return EKFVIO_ESTATE;
+
+int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float* init_px, int32_t count, float* out_px,
+                            uint8_t* status) {
+    if (!f || !prev_px || !init_px || count < 0) return EKFVIO_EINVAL;
+    if (count > f->cfg.max_features) return EKFVIO_ECAPACITY;
+    if (!f->frames[0].valid || !f->frames[1].valid) {
+        f->last_error = "KLT needs two frames";
+        return EKFVIO_ESTATE;
+    }
+    if (count == 0) return EKFVIO_OK;
+    HIPK(f, hipSetDevice(f->device));
+    HIPK(f, hipMemcpyAsync(f->klt_prev_px, prev_px, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    HIPK(f, hipMemcpyAsync(f->klt_next_px, init_px, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    track_points_device(f, count);
+    if (out_px) HIPK(f, hipMemcpyAsync(out_px, f->klt_next_px, sizeof(float) * 2 * count, hipMemcpyDeviceToHost, f->stream));
+    if (status) HIPK(f, hipMemcpyAsync(status, f->klt_status, count, hipMemcpyDeviceToHost, f->stream));
+    HIPK(f, hipGetLastError());
+    HIPK(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
 }
-int ekfvio_step_image(ekfvio_filter* f, double, const uint8_t*, int32_t, int32_t, int32_t, const float*) {
-    if (f) f->last_error = "KLT not built";
-    return EKFVIO_ESTATE;
+
+// Test hook: copies pyramid level `level` of the current frame (interior only) to the host.
+int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h, uint8_t* img, int16_t* deriv) {
+    if (!f || level < 0) return EKFVIO_EINVAL;
+    const KltFrame& fr = f->frames[f->cur];
+    if (!fr.valid || level >= fr.levels) return EKFVIO_ESTATE;
+    HIPK(f, hipSetDevice(f->device));
+    const int lw = fr.w[level], lh = fr.h[level], pitch = level_pitch(lw);
+    if (w) *w = lw;
+    if (h) *h = lh;
+    if (img)
+        HIPK(f, hipMemcpy2DAsync(img, lw, fr.img[level] + (size_t)KLT_BORDER * pitch + KLT_BORDER, pitch, lw, lh,
+                                 hipMemcpyDeviceToHost, f->stream));
+    if (deriv)
+        HIPK(f, hipMemcpy2DAsync(deriv, (size_t)lw * 4, fr.deriv[level] + ((size_t)KLT_BORDER * pitch + KLT_BORDER) * 2,
+                                 (size_t)pitch * 4, (size_t)lw * 4, lh, hipMemcpyDeviceToHost, f->stream));
+    HIPK(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
 }
+
+// EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) minus ROS publishing and
+// FAST replenishment (the caller adds landmarks with ekfvio_add_features).
+int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                      const float K[9]) {
+    if (!f) return EKFVIO_EINVAL;
+    const bool first = !f->frames[f->cur].valid;
+    if (!first && f->have_stamp && !(stamp - f->t_stamp >= 0)) return EKFVIO_EINVAL;  // ROS_ASSERT(dt >= 0)
+    int rc = ekfvio_klt_push_frame(f, image, width, height, stride, K);
+    if (rc != EKFVIO_OK) return rc;
+    if (first) {
+        // first frame: remember the stamp (tc_ekf.t = f.t) and return; the caller replenishes
+        if (!f->have_stamp) {
+            f->t_stamp = stamp;
+            f->have_stamp = true;
+        }
+        return EKFVIO_OK;
+    }
+    const float dt = (float)(stamp - f->t_stamp);
+    launch_predict(f, dt);
+    f->t_stamp = stamp;
+    f->have_stamp = true;
+    int status = EKFVIO_OK;
+    if (f->N > 0) {  // "run update if we have enough features" (EKFVIO.cpp:166)
+        rc = klt_track_device(f);
+        if (rc != EKFVIO_OK) return rc;
+        std::vector<uint8_t> hp(f->N);
+        HIPK(f, hipMemcpyAsync(hp.data(), f->pass, f->N, hipMemcpyDeviceToHost, f->stream));
+        HIPK(f, hipStreamSynchronize(f->stream));
+        int m = 0;
+        for (int i = 0; i < f->N; i++) m += hp[i] ? 2 : 0;
+        launch_update(f, m, f->zmeas, f->Rmeas, f->pass);
+        HIPK(f, hipMemcpyAsync(f->h_info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+        HIPK(f, hipStreamSynchronize(f->stream));
+        if (f->h_info[0]) {
+            status = EKFVIO_ENUMERIC;
+            HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
+        }
+    }
+    HIPK(f, hipGetLastError());
+    return status;
 }
+
+}  // extern "C"

@@ -205,3 +205,81 @@ class TightlyCoupledEKF:
         info = C.c_int32(0)
         self._chk(self.lib.ekfvio_test_cholesky_solve(self.h, m, nr, _fp(Sc), _fp(Cc), _fp(L), _fp(X), C.byref(info)))
         return L.T.copy(), X.T.copy(), info.value
+
+
+class KLTTracker:
+    """Host mirror of the reference's `class KLTTracker` (include/ekf_vio/KLTTracker.h:88-90).
+    The two most recent frames live on the device inside the filter handle (the reference
+    keeps them in EKFVIO::frame_buffer, depth 2)."""
+
+    def __init__(self, ekf):
+        self.ekf = ekf
+        self.lib = ekf.lib
+
+    def push_frame(self, img, K):
+        """Frame(img, K, ...) -> device pyramid; the previous current frame becomes `lf`."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        self.ekf._chk(self.lib.ekfvio_klt_push_frame(self.ekf.h, _u8(img), w, h, w, _fp(K)))
+
+    def findNewFeaturePositions(self):
+        """(measured_positions[N,2], estimated_uncertainty[N,4], passed[N]) for the filter's
+        landmarks, tracked from the previous into the current frame (KLTTracker.cpp:29-95)."""
+        N = self.ekf.num_features
+        z = np.zeros((N, 2), np.float32)
+        R = np.zeros((N, 4), np.float32)
+        p = np.zeros(N, np.uint8)
+        self.ekf._chk(self.lib.ekfvio_klt_track(self.ekf.h, _fp(z), _fp(R), _u8(p)))
+        return z, R, p
+
+    def track_points(self, prev_px, init_px):
+        """calcOpticalFlowPyrLK(prev, cur, prev_px, init_px, OPTFLOW_USE_INITIAL_FLOW) in pixels."""
+        pp = np.ascontiguousarray(prev_px, dtype=np.float32).reshape(-1, 2)
+        ii = np.ascontiguousarray(init_px, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros_like(pp)
+        st = np.zeros(pp.shape[0], np.uint8)
+        self.ekf._chk(self.lib.ekfvio_klt_track_points(self.ekf.h, _fp(pp), _fp(ii), pp.shape[0], _fp(out), _u8(st)))
+        return out, st
+
+    def level(self, l):
+        w, h = C.c_int32(0), C.c_int32(0)
+        self.ekf._chk(self.lib.ekfvio_klt_get_level(self.ekf.h, l, C.byref(w), C.byref(h), None, None))
+        img = np.zeros((h.value, w.value), np.uint8)
+        der = np.zeros((h.value, w.value, 2), np.int16)
+        self.ekf._chk(self.lib.ekfvio_klt_get_level(self.ekf.h, l, C.byref(w), C.byref(h), _u8(img),
+                                                    der.ctypes.data_as(C.POINTER(C.c_int16))))
+        return img, der
+
+
+class EKFVIO:
+    """Host mirror of the step sequence of EKFVIO::addFrame / updateStateWithNewImage
+    (include/ekf_vio/EKFVIO.cpp:139-219) without ROS: frames in, odometry + landmark cloud out.
+    Landmark replenishment (FAST, EKFVIO.cpp:224-311) stays with the caller."""
+
+    def __init__(self, **kw):
+        self.tc_ekf = TightlyCoupledEKF(**kw)
+        self.tracker = KLTTracker(self.tc_ekf)
+
+    def addFrame(self, stamp, img, K):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        return self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_step_image(self.tc_ekf.h, float(stamp), _u8(img), w, h, w, _fp(K)),
+                                allow=(capi.ENUMERIC,))
+
+    def imu_callback(self, stamp, gyro, accel):
+        """EKFVIO::imu_callback (EKFVIO.cpp:113-115): a logging stub in the reference."""
+        g = np.ascontiguousarray(gyro, dtype=np.float32)
+        a = np.ascontiguousarray(accel, dtype=np.float32)
+        self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_imu(self.tc_ekf.h, float(stamp), _fp(g), _fp(a)))
+
+    def odometry(self):
+        """What publishOdometry sends (EKFVIO.cpp:444-477): position, orientation (w,x,y,z), twist."""
+        b = self.tc_ekf.base_mu
+        return dict(position=b[0:3], orientation_wxyz=b[3:7], linear=b[7:10], angular=b[10:13])
+
+    def points(self):
+        """publishPoints (EKFVIO.cpp:479-518): camera-frame xyz = (u/rho, v/rho, 1/rho) per landmark."""
+        f = self.tc_ekf.get_state()["feat_mu"]
+        return np.stack([f[:, 0] / f[:, 2], f[:, 1] / f[:, 2], 1.0 / f[:, 2]], axis=1)

@@ -128,6 +128,10 @@ int ekfvio_klt_track(ekfvio_filter* f, float* z2N, float* R4N, uint8_t* passN);
 int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float* init_px, int32_t count,
                             float* out_px, uint8_t* status);
 
+/* Test hook: interior of pyramid level `level` of the current frame (8-bit image, w*h, and
+ * interleaved int16 Scharr dx,dy, w*h*2).  Either output may be NULL. */
+int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h, uint8_t* img, int16_t* deriv);
+
 /* EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) without the ROS
  * publishing: first frame only stores the image and stamp; later frames run
  * process(dt = stamp - t), then KLT + update if landmarks exist.  Landmark replenishment

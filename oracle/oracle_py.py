@@ -60,6 +60,14 @@ def _declare(lib):
         g("check_sigma").argtypes = [vp, tp, tp]
         g("time_steps").argtypes = [vp, i32, ct, tp, tp, u8p]
         g("time_steps").restype = C.c_double
+    i16p, fpp = C.POINTER(C.c_int16), C.POINTER(C.c_float)
+    lib.orc_klt_frame_create.restype = vp
+    lib.orc_klt_frame_create.argtypes = [u8p, i32, i32, i32, i32, i32]
+    lib.orc_klt_frame_destroy.argtypes = [vp]
+    lib.orc_klt_levels.argtypes = [vp]
+    lib.orc_klt_level_size.argtypes = [vp, i32, ip, ip]
+    lib.orc_klt_get_level.argtypes = [vp, i32, u8p, i16p]
+    lib.orc_klt_track.argtypes = [vp, vp, fpp, fpp, i32, i32, i32, C.c_float, C.c_float, i32, u8p, ip]
     lib.orc_set_threads.argtypes = [i32]
     lib.orc_max_threads.restype = i32
 
@@ -188,3 +196,48 @@ class OracleFilter:
         p = np.ascontiguousarray(passed, dtype=np.uint8).reshape(N)
         return float(self._f("time_steps")(self.h, int(steps), self.ct(dt), _p(z, self.ct), _p(R, self.ct),
                                            _p(p, C.c_uint8)))
+
+
+class KltFrame:
+    """Pyramid + Scharr derivatives of one 8-bit frame (restated OpenCV buildOpticalFlowPyramid)."""
+
+    def __init__(self, img, win=21, max_level=3):
+        self.lib = oracle_lib()
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self.h_, self.w_ = img.shape
+        self.win = win
+        self.p = C.c_void_p(self.lib.orc_klt_frame_create(_p(img, C.c_uint8), self.w_, self.h_, self.w_, win, max_level))
+
+    def __del__(self):
+        try:
+            if self.p:
+                self.lib.orc_klt_frame_destroy(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+    @property
+    def levels(self):
+        return int(self.lib.orc_klt_levels(self.p))
+
+    def level(self, l):
+        w, h = C.c_int(0), C.c_int(0)
+        self.lib.orc_klt_level_size(self.p, l, C.byref(w), C.byref(h))
+        img = np.zeros((h.value, w.value), np.uint8)
+        der = np.zeros((h.value, w.value, 2), np.int16)
+        self.lib.orc_klt_get_level(self.p, l, _p(img, C.c_uint8), _p(der, C.c_int16))
+        return img, der
+
+
+def klt_track(prev, nxt, prev_px, init_px, win=21, max_iter=30, epsilon=0.01, min_eig=1e-4, accum_mode=0):
+    """calcOpticalFlowPyrLK(prev, next, prev_px, init_px, ..., OPTFLOW_USE_INITIAL_FLOW) restated.
+    Returns (next_px[n,2] float32, status[n] uint8, iterations[n])."""
+    lib = oracle_lib()
+    pp = np.ascontiguousarray(prev_px, dtype=np.float32).reshape(-1, 2)
+    nn = np.array(init_px, dtype=np.float32, order="C", copy=True).reshape(-1, 2)
+    n = pp.shape[0]
+    st = np.zeros(n, np.uint8)
+    it = np.zeros(n, np.int32)
+    lib.orc_klt_track(prev.p, nxt.p, _p(pp, C.c_float), _p(nn, C.c_float), n, win, max_iter, epsilon, min_eig,
+                      accum_mode, _p(st, C.c_uint8), it.ctypes.data_as(C.POINTER(C.c_int)))
+    return nn, st, it

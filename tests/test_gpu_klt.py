@@ -1,0 +1,142 @@
+"""GPU KLT parity (BASELINE config 1: 640x480 test images, KLT + N=64-landmark update).
+The HIP pyramid / Scharr / tracker are compared with the oracle bit for bit (integer images
+and derivatives; tracked positions are float32 results of identical scalar arithmetic on
+exactly accumulated integer sums)."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from ekf_vio_amd import EKFVIO, KLTTracker, TightlyCoupledEKF, capi, EkfvioError
+from oracle import KltFrame, OracleFilter, klt_track
+
+pytestmark = pytest.mark.gpu
+IMG = os.path.join(os.path.dirname(__file__), "golden", "images")
+K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)  # fx=fy=500
+
+
+def grey(name):
+    return np.asarray(Image.open(os.path.join(IMG, name + "_gray.png")))
+
+
+def grid_points(n=8):
+    xs, ys = np.linspace(80, 560, n), np.linspace(60, 420, n)
+    return np.array([[x, y] for y in ys for x in xs], np.float32)
+
+
+@pytest.mark.parametrize("crop", [None, (251, 333), (120, 160)])
+def test_pyramid_and_derivatives_bit_exact(crop):
+    img = grey("640_480_test")
+    if crop:
+        img = img[:crop[0], :crop[1]].copy()
+    g = TightlyCoupledEKF(max_features=4)
+    t = KLTTracker(g)
+    t.push_frame(img, K)
+    o = KltFrame(img)
+    for l in range(o.levels):
+        gi, gd = t.level(l)
+        oi, od = o.level(l)
+        assert np.array_equal(gi, oi), ("image", l)
+        assert np.array_equal(gd, od), ("deriv", l)
+    with pytest.raises(EkfvioError):
+        t.level(o.levels)  # no such level on the device either
+    g.close()
+
+
+@pytest.mark.parametrize("second", ["640_480_moved_test", "640_480_shear_test", "640_480_test"])
+def test_tracked_points_bit_exact_and_flow(second):
+    a, b = grey("640_480_test"), grey(second)
+    g = TightlyCoupledEKF(max_features=256)
+    t = KLTTracker(g)
+    t.push_frame(a, K), t.push_frame(b, K)
+    pts = np.vstack([grid_points(8), grid_points(13)[:150],
+                     [[5.0, 5.0], [-40.0, 100.0], [700.0, 100.0], [639.0, 479.0], [320.5, 0.25]]]).astype(np.float32)
+    A, B = KltFrame(a), KltFrame(b)
+    on, os_, _ = klt_track(A, B, pts, pts.copy())
+    gn, gs = t.track_points(pts, pts.copy())
+    assert np.array_equal(gs, os_)
+    assert np.array_equal(gn, on), float(np.abs(gn - on).max())
+    if second == "640_480_moved_test":
+        ok = gs[:64] == 1
+        assert ok.sum() >= 62
+        assert np.abs(np.median((gn - pts)[:64][ok], axis=0) - np.array([-21.0, -7.0])).max() < 2e-3
+    g.close()
+
+
+def test_small_image_reduces_levels_and_flat_patch_fails():
+    img = grey("640_480_test")[::4, ::4].copy()  # 160x120: level 3 would be 20x15 <= window
+    g = TightlyCoupledEKF(max_features=8)
+    t = KLTTracker(g)
+    t.push_frame(img, K), t.push_frame(np.roll(img, 2, axis=1), K)
+    o1, o2 = KltFrame(img), KltFrame(np.roll(img, 2, axis=1))
+    assert o1.levels == 3
+    pts = np.array([[40.0, 40.0], [80.0, 60.0], [120.0, 90.0]], np.float32)
+    on, os_, _ = klt_track(o1, o2, pts, pts.copy())
+    gn, gs = t.track_points(pts, pts.copy())
+    assert np.array_equal(gs, os_) and np.array_equal(gn, on)
+    flat = np.full((120, 160), 90, np.uint8)
+    t.push_frame(flat, K), t.push_frame(flat, K)
+    _, st = t.track_points([[80.0, 60.0]], [[80.0, 60.0]])
+    assert list(st) == [0]
+    g.close()
+
+
+def test_klt_requires_two_frames():
+    g = TightlyCoupledEKF(max_features=4)
+    t = KLTTracker(g)
+    g.addNewFeatures([[0.1, 0.1]])
+    with pytest.raises(EkfvioError) as e:
+        t.findNewFeaturePositions()
+    assert e.value.code == capi.ESTATE
+    g.close()
+
+
+def _metric(px):
+    """Feature::pixel2Metric with the reference's K indexing quirk (cx = cy = 0), Feature.h:60-62."""
+    return np.stack([px[:, 0] / K[0], px[:, 1] / K[4]], axis=1).astype(np.float32)
+
+
+def test_config1_klt_plus_64_landmark_update():
+    """addFrame sequence (EKFVIO.cpp:139-219) on the reference image pair with 64 landmarks:
+    first frame stores image + stamp, second frame runs process(dt) -> KLT -> update."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    px = grid_points(8)
+    uv = _metric(px)
+    v = EKFVIO(max_features=64)
+    assert v.addFrame(10.0, a, K) == capi.OK
+    v.tc_ekf.addNewFeatures(uv)  # stands in for replenishFeatures
+    v.imu_callback(10.01, [0, 0, 0], [0, 0, 9.8])  # logging stub in the reference
+    o = OracleFilter(np.float32)
+    o.add_new_features(uv)
+    rc = v.addFrame(10.0 + 1.0 / 30.0, b, K)
+    assert rc in (capi.OK, capi.ENUMERIC)
+    # oracle sequence: process, KLT (prev = last_klt in pixels, init = predicted landmark), update
+    dt = np.float32(np.float64(10.0 + 1.0 / 30.0) - np.float64(10.0))
+    o.process(dt)
+    st = o.get_state()
+    prev_px = np.stack([st["last_klt"][:, 0] * K[0], st["last_klt"][:, 1] * K[4]], axis=1).astype(np.float32)
+    init_px = np.stack([K[0] * st["feat_mu"][:, 0], K[4] * st["feat_mu"][:, 1]], axis=1).astype(np.float32)
+    nxt, status, _ = klt_track(KltFrame(a), KltFrame(b), prev_px, init_px)
+    kp = 11
+    passed = (status == 1) & ~((nxt[:, 0] < kp) | (nxt[:, 1] < kp) | (640 - nxt[:, 0] < kp) | (480 - nxt[:, 1] < kp))
+    z = _metric(nxt)
+    R = np.zeros((64, 4), np.float32)
+    R[:, 0] = np.float32(1e-5) * np.float32((1.0 / np.float64(K[0])) ** 2)
+    R[:, 3] = np.float32(1e-5) * np.float32((1.0 / np.float64(K[4])) ** 2)
+    o64 = OracleFilter(np.float64)
+    o64.set_state(st)
+    o.update(z, R, passed.astype(np.uint8)), o64.update(z, R, passed.astype(np.uint8))
+    sg, so, s64 = v.tc_ekf.get_state(), o.get_state(), o64.get_state()
+    assert passed.sum() >= 60
+    assert np.array_equal(sg["del_flag"], so["del_flag"])           # same landmarks failed
+    assert np.array_equal(sg["last_klt"], so["last_klt"])           # KLT results bit-exact through the ABI
+    eg = np.abs(sg["base_mu"].astype(np.float64) - s64["base_mu"]).max()
+    eo = np.abs(so["base_mu"].astype(np.float64) - s64["base_mu"]).max()
+    assert eg <= 12 * eo + 2e-5, (eg, eo)   # first update from the raw prior (see test_gpu_parity)
+    rel = lambda x, y: np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y)
+    assert rel(sg["Sigma"], s64["Sigma"]) <= 4 * rel(so["Sigma"], s64["Sigma"]) + 2e-6
+    od = v.odometry()
+    assert od["position"].shape == (3,) and abs(np.linalg.norm(od["orientation_wxyz"]) - 1) < 1e-6
+    assert v.points().shape == (64, 3)
+    v.tc_ekf.close()
