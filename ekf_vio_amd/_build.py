@@ -39,5 +39,25 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(_HERE, "host")
+REPLAY_PATH = os.path.join(LIB_DIR, "ekfvio_replay")
+
+
+def build_host(force=False, verbose=False):
+    """C++ host shim + ROS-free replay driver (g++, links the C-ABI library only)."""
+    src = os.path.join(HOST_DIR, "replay_main.cpp")
+    deps = [src, os.path.join(HOST_DIR, "ekfvio.hpp"), LIB_PATH]
+    if (not force and os.path.exists(REPLAY_PATH)
+            and all(os.path.getmtime(REPLAY_PATH) >= os.path.getmtime(d) for d in deps)):
+        return REPLAY_PATH
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", REPLAY_PATH, src, "-L" + LIB_DIR, "-lekfvio_hip",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return REPLAY_PATH
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -1,0 +1,175 @@
+// ekf_vio_amd/host/ekfvio.hpp — header-only C++ host shim over the C-ABI (include/ekfvio.h).
+//
+// Mirrors the three classes EKFVIO::addFrame touches in the reference, with the same member
+// names and argument meaning, so that the reference's node (include/ekf_vio/EKFVIO.cpp) can
+// swap its `TightlyCoupledEKF tc_ekf; KLTTracker tracker;` members (EKFVIO.h:70-72) for these
+// and keep its call sites:
+//   reference                                              here
+//   tc_ekf.process(dt)                    EKFVIO.cpp:163   TightlyCoupledEKF::process
+//   tc_ekf.previousFeaturePositionVector  EKFVIO.cpp:216   (kept on the device; getter provided)
+//   tracker.findNewFeaturePositions(...)  EKFVIO.cpp:216   KLTTracker::findNewFeaturePositions
+//   tc_ekf.updateWithFeaturePositions     EKFVIO.cpp:218   TightlyCoupledEKF::updateWithFeaturePositions
+//   tc_ekf.addNewFeatures                 EKFVIO.cpp:308   TightlyCoupledEKF::addNewFeatures
+// Eigen/OpenCV types are replaced by plain structs with the same memory layout
+// (Eigen::Vector2f = 2 floats, Eigen::Matrix2f = 4 floats column-major, cv::Mat 8UC1 = pointer
+// + step).  Errors the reference would ROS_ASSERT on surface as ekfvio::Error.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ekfvio.h"
+
+namespace ekfvio {
+
+using Vector2f = std::array<float, 2>;
+using Matrix2f = std::array<float, 4>;  // column-major
+using Vector3f = std::array<float, 3>;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// Frame.h:25-41 without OpenCV: 8-bit single-channel image + intrinsics + stamp.
+struct Frame {
+    const uint8_t* img = nullptr;
+    int cols = 0, rows = 0, step = 0;
+    std::array<float, 9> K{};  // row-major, as sensor_msgs/CameraInfo.K
+    double t = 0;
+};
+
+class TightlyCoupledEKF {
+   public:
+    explicit TightlyCoupledEKF(int max_features = 100, int device = 0, const ekfvio_config* cfg = nullptr) {
+        ekfvio_config c;
+        if (cfg) c = *cfg;
+        else ekfvio_default_config(&c);
+        if (!cfg) c.max_features = max_features;
+        int rc = ekfvio_create(&c, device, nullptr, &h_);
+        if (rc != EKFVIO_OK) {
+            std::string msg = h_ ? ekfvio_last_error(h_) : "ekfvio_create failed";
+            if (h_) ekfvio_destroy(h_);
+            h_ = nullptr;
+            throw Error(rc, msg);
+        }
+    }
+    ~TightlyCoupledEKF() {
+        if (h_) ekfvio_destroy(h_);
+    }
+    TightlyCoupledEKF(const TightlyCoupledEKF&) = delete;
+    TightlyCoupledEKF& operator=(const TightlyCoupledEKF&) = delete;
+
+    void initializeBaseState() { chk(ekfvio_reset(h_)); }
+    void addNewFeatures(const std::vector<Vector2f>& new_homogenous_features) {
+        chk(ekfvio_add_features(h_, new_homogenous_features.empty() ? nullptr : new_homogenous_features[0].data(),
+                                (int)new_homogenous_features.size()));
+    }
+    void process(float dt) { chk(ekfvio_process(h_, dt)); }
+    // returns false when the factorisation met a non-positive pivot (reference: ROS_ERROR_COND, continues)
+    bool updateWithFeaturePositions(const std::vector<Vector2f>& measured_positions,
+                                    const std::vector<Matrix2f>& estimated_covariance, const std::vector<uint8_t>& pass) {
+        if (measured_positions.size() != estimated_covariance.size() || pass.size() != estimated_covariance.size())
+            throw Error(EKFVIO_EINVAL, "size mismatch (TightlyCoupledEKF.cpp:478)");
+        int rc = ekfvio_update(h_, measured_positions.empty() ? nullptr : measured_positions[0].data(),
+                               estimated_covariance.empty() ? nullptr : estimated_covariance[0].data(), pass.data(),
+                               (int)pass.size());
+        if (rc == EKFVIO_ENUMERIC) return false;
+        chk(rc);
+        return true;
+    }
+    std::vector<int> formFeatureMeasurementMap(const std::vector<uint8_t>& measured) const {
+        std::vector<int> idx(2 * measured.size() + 1);
+        int rows = 0;
+        chk(ekfvio_measurement_map(h_, measured.data(), (int)measured.size(), idx.data(), &rows));
+        idx.resize(rows);
+        return idx;
+    }
+    std::vector<Vector2f> previousFeaturePositionVector() {
+        std::vector<Vector2f> out(numFeatures());
+        chk(ekfvio_get_features(h_, nullptr, out.empty() ? nullptr : out[0].data(), nullptr));
+        return out;
+    }
+    Matrix2f getFeatureHomogenousCovariance(int index) {
+        Matrix2f m;
+        chk(ekfvio_get_feature_cov(h_, index, m.data()));
+        return m;
+    }
+    float getFeatureDepthVariance(int index) {
+        float v = 0;
+        chk(ekfvio_get_depth_variance(h_, index, &v));
+        return v;
+    }
+    // checkSigma (TightlyCoupledEKF.cpp:699-714): true iff diag >= 0 and |S_ij - S_ji| <= 1e-3
+    bool checkSigma(float* min_diag = nullptr, float* max_asym = nullptr) {
+        float a = 0, b = 0;
+        chk(ekfvio_check_sigma(h_, &a, &b));
+        if (min_diag) *min_diag = a;
+        if (max_asym) *max_asym = b;
+        return a >= 0 && b <= 1e-3f;
+    }
+    std::array<float, EKFVIO_BASE_STATE_SIZE> base_mu() {
+        std::array<float, EKFVIO_BASE_STATE_SIZE> b;
+        chk(ekfvio_get_base_mu(h_, b.data()));
+        return b;
+    }
+    std::vector<Vector3f> featureMus() {
+        std::vector<Vector3f> out(numFeatures());
+        chk(ekfvio_get_features(h_, out.empty() ? nullptr : out[0].data(), nullptr, nullptr));
+        return out;
+    }
+    int numFeatures() const { return ekfvio_num_features(h_); }
+    int dim() const { return ekfvio_dim(h_); }
+    ekfvio_filter* handle() { return h_; }
+
+    void chk(int rc) const {
+        if (rc != EKFVIO_OK) throw Error(rc, ekfvio_last_error(h_));
+    }
+
+   private:
+    ekfvio_filter* h_ = nullptr;
+};
+
+class KLTTracker {
+   public:
+    explicit KLTTracker(TightlyCoupledEKF& ekf) : ekf_(ekf) {}
+    // Uploads `cf`; the previously pushed frame becomes `lf` (the reference passes both by reference).
+    void pushFrame(const Frame& cf) {
+        ekf_.chk(ekfvio_klt_push_frame(ekf_.handle(), cf.img, cf.cols, cf.rows, cf.step, cf.K.data()));
+    }
+    void findNewFeaturePositions(std::vector<Vector2f>& measured_positions, std::vector<Matrix2f>& estimated_uncertainty,
+                                 std::vector<uint8_t>& passed) {
+        const int N = ekf_.numFeatures();
+        measured_positions.resize(N);
+        estimated_uncertainty.resize(N);
+        passed.resize(N);
+        ekf_.chk(ekfvio_klt_track(ekf_.handle(), N ? measured_positions[0].data() : nullptr,
+                                  N ? estimated_uncertainty[0].data() : nullptr, passed.data()));
+    }
+
+   private:
+    TightlyCoupledEKF& ekf_;
+};
+
+// The step sequence of EKFVIO::addFrame (EKFVIO.cpp:139-196) with the ROS plumbing removed.
+class EKFVIO {
+   public:
+    explicit EKFVIO(int max_features = 100, int device = 0) : tc_ekf(max_features, device), tracker(tc_ekf) {}
+    TightlyCoupledEKF tc_ekf;
+    KLTTracker tracker;
+
+    // returns false on a numeric warning (see updateWithFeaturePositions)
+    bool addFrame(const Frame& f) {
+        int rc = ekfvio_step_image(tc_ekf.handle(), f.t, f.img, f.cols, f.rows, f.step, f.K.data());
+        if (rc == EKFVIO_ENUMERIC) return false;
+        tc_ekf.chk(rc);
+        return true;
+    }
+    void imu_callback(double stamp, const Vector3f& gyro, const Vector3f& accel) {
+        tc_ekf.chk(ekfvio_imu(tc_ekf.handle(), stamp, gyro.data(), accel.data()));
+    }
+};
+
+}  // namespace ekfvio

@@ -1,0 +1,110 @@
+// ekf_vio_amd/host/replay_main.cpp — ROS-free replay / smoke driver for the C++ host shim.
+//
+// Runs the synthetic closed loop of the reference's test/analyzeEKFSimulation.cpp:10-125
+// (N landmarks, truth integrated with the filter's own motion model, perfect projections,
+// R = 1e-5 I, every landmark measured) through ekfvio::TightlyCoupledEKF and prints the
+// final odometry next to the ground truth, the checkSigma numbers and the step rate.
+// Usage: ekfvio_replay [landmarks=256] [frames=300] [seed=0] [dt=0.0333333]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "ekfvio.hpp"
+
+namespace {
+struct SplitMix64 {
+    uint64_t s;
+    uint64_t next() {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform(double lo, double hi) { return lo + (hi - lo) * ((next() >> 11) * (1.0 / 9007199254740992.0)); }
+    double gaussian(double sigma) {
+        double u1 = std::fmax(uniform(0, 1), 1e-300), u2 = uniform(0, 1);
+        return sigma * std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+    }
+};
+struct V3 {
+    double x, y, z;
+};
+struct Q {
+    double w, x, y, z;
+};
+V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+V3 rot(Q q, V3 v) {
+    V3 qv{q.x, q.y, q.z}, uv = cross(qv, v);
+    uv = {2 * uv.x, 2 * uv.y, 2 * uv.z};
+    V3 c = cross(qv, uv);
+    return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+Q mul(Q a, Q b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? std::atoi(argv[1]) : 256;
+    const int frames = argc > 2 ? std::atoi(argv[2]) : 300;
+    const uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 0;
+    const float dt = argc > 4 ? (float)std::atof(argv[4]) : (float)(1.0 / 30.0);
+    try {
+        ekfvio::TightlyCoupledEKF ekf(N, 0);
+        SplitMix64 rng{seed};
+        std::vector<V3> pts(N);
+        std::vector<ekfvio::Vector2f> uv(N);
+        for (int i = 0; i < N; i++) {
+            double z = 0.5 + rng.gaussian(0.01);
+            double x = rng.uniform(-1.5, 1.5) * z, y = rng.uniform(-1.5, 1.5) * z;
+            pts[i] = {x, y, z};
+            uv[i] = {(float)(x / z), (float)(y / z)};
+        }
+        ekf.addNewFeatures(uv);
+        V3 pos{0, 0, 0}, vel{-0.1, 0, -0.1}, acc{0, 0, 0}, om{0, 0.1, 0};
+        Q quat{1, 0, 0, 0};
+        std::vector<ekfvio::Vector2f> z(N);
+        std::vector<ekfvio::Matrix2f> R(N, ekfvio::Matrix2f{1e-5f, 0, 0, 1e-5f});
+        std::vector<uint8_t> pass(N, 1);
+        bool numeric_ok = true;
+        auto t0 = std::chrono::steady_clock::now();
+        for (int s = 0; s < frames; s++) {
+            const double d = dt;
+            V3 tr{d * vel.x + 0.5 * d * d * acc.x, d * vel.y + 0.5 * d * d * acc.y, d * vel.z + 0.5 * d * d * acc.z};
+            V3 dp = rot(quat, tr);
+            pos = {pos.x + dp.x, pos.y + dp.y, pos.z + dp.z};
+            const double on = std::sqrt(om.x * om.x + om.y * om.y + om.z * om.z), th = d * on;
+            Q dq = on < 1e-10 ? Q{1, 0, 0, 0} : Q{std::cos(th / 2), om.x / on * std::sin(th / 2), om.y / on * std::sin(th / 2),
+                                                   om.z / on * std::sin(th / 2)};
+            Q dqi{dq.w, -dq.x, -dq.y, -dq.z};
+            vel = rot(dqi, {vel.x + d * acc.x, vel.y + d * acc.y, vel.z + d * acc.z});
+            acc = rot(dqi, acc);
+            quat = mul(quat, dq);
+            Q qi{quat.w, -quat.x, -quat.y, -quat.z};
+            for (int i = 0; i < N; i++) {
+                V3 fp = rot(qi, {pts[i].x - pos.x, pts[i].y - pos.y, pts[i].z - pos.z});
+                z[i] = {(float)(fp.x / fp.z), (float)(fp.y / fp.z)};
+            }
+            ekf.process(dt);
+            numeric_ok &= ekf.updateWithFeaturePositions(z, R, pass);
+        }
+        auto b = ekf.base_mu();
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        float md = 0, ma = 0;
+        ekf.checkSigma(&md, &ma);
+        std::printf("landmarks %d frames %d steps_per_s %.1f numeric_ok %d\n", N, frames, frames / el, (int)numeric_ok);
+        std::printf("est_pos %.6f %.6f %.6f truth_pos %.6f %.6f %.6f\n", b[0], b[1], b[2], pos.x, pos.y, pos.z);
+        std::printf("est_vel %.6f %.6f %.6f truth_vel %.6f %.6f %.6f\n", b[7], b[8], b[9], vel.x, vel.y, vel.z);
+        std::printf("est_quat %.6f %.6f %.6f %.6f truth_quat %.6f %.6f %.6f %.6f\n", b[3], b[4], b[5], b[6], quat.w, quat.x,
+                    quat.y, quat.z);
+        std::printf("min_diag %.3e max_asym %.3e\n", md, ma);
+        const double perr = std::fmax(std::fabs(b[0] - pos.x), std::fmax(std::fabs(b[1] - pos.y), std::fabs(b[2] - pos.z)));
+        return (frames >= 60 && perr > 0.02) || md < 0 ? 2 : 0;
+    } catch (const ekfvio::Error& e) {
+        std::fprintf(stderr, "ekfvio error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+}
