@@ -106,7 +106,7 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     f->n_cap = EKF_BASE + 3 * maxf;
     f->ldp = round_up(f->n_cap, 64);
     f->m_cap = round_up(2 * maxf > 0 ? 2 * maxf : 1, 64);
-    const size_t pp = (size_t)f->ldp * f->ldp, pm = (size_t)f->ldp * f->m_cap, mm = (size_t)f->m_cap * f->m_cap;
+    const size_t pp = (size_t)f->ldp * f->ldp, pm = (size_t)f->ldp * f->m_cap;
     HIPC(f, dev_alloc(f->stream, &f->mu, f->ldp));
     HIPC(f, dev_alloc(f->stream, &f->mu_next, f->ldp));
     HIPC(f, dev_alloc(f->stream, &f->last_klt, 2 * (size_t)maxf));
@@ -123,8 +123,9 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     HIPC(f, dev_alloc(f->stream, &f->pass, (size_t)maxf));
     HIPC(f, dev_alloc(f->stream, &f->yres, (size_t)f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Rm, 2 * (size_t)f->m_cap));
-    HIPC(f, dev_alloc(f->stream, &f->S, mm));
-    HIPC(f, dev_alloc(f->stream, &f->L, mm));
+    f->ld_aug = f->m_cap + f->ldp + f->m_cap;
+    HIPC(f, dev_alloc(f->stream, &f->Saug, (size_t)f->ld_aug * f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Km, pm));
     HIPC(f, dev_alloc(f->stream, &f->Wt, pm));
@@ -143,7 +144,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     hipSetDevice(f->device);
     hipStreamSynchronize(f->stream);
     void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
-                    f->idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->S,  f->L,  f->Linv, f->Km,
+                    f->idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km,
                     f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -409,7 +410,7 @@ int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int
     HIPC(f, hipSetDevice(f->device));
     // device copies padded to the kernel's contract (64-row/col slack, K to 16, zero fill);
     // packed on the host so that only flat copies are issued
-    const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 16);
+    const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 32);
     const int brows = transB ? Np : Kp, bcols = transB ? Kp : Np;
     std::vector<float> hA((size_t)Mp * Kp, 0.f), hB((size_t)brows * bcols, 0.f), hC((size_t)Mp * Np, 0.f);
     for (int k = 0; k < K; k++)
@@ -436,39 +437,86 @@ int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int
     return EKFVIO_OK;
 }
 
+// Times `reps` back-to-back launches of the GEMM at one shape (operands resident, random
+// fill); returns the mean launch-to-launch time in microseconds.  variant selects a tile
+// configuration (0 = production).
+int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int32_t M, int32_t N, int32_t K,
+                           int32_t reps, int32_t variant, double* mean_us) {
+    if (!f || M <= 0 || N <= 0 || K <= 0 || reps <= 0 || !mean_us) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 32);
+    const int brows = transB ? Np : Kp, bcols = transB ? Kp : Np;
+    std::vector<float> hA((size_t)Mp * Kp), hB((size_t)brows * bcols), hC((size_t)Mp * Np);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hA) v = rnd();
+    for (auto& v : hB) v = rnd();
+    for (auto& v : hC) v = rnd();
+    float *dA, *dB, *dC;
+    HIPC(f, dev_alloc(f->stream, &dA, hA.size()));
+    HIPC(f, dev_alloc(f->stream, &dB, hB.size()));
+    HIPC(f, dev_alloc(f->stream, &dC, hC.size()));
+    HIPC(f, hipMemcpyAsync(dA, hA.data(), sizeof(float) * hA.size(), hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpyAsync(dB, hB.data(), sizeof(float) * hB.size(), hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipMemcpyAsync(dC, hC.data(), sizeof(float) * hC.size(), hipMemcpyHostToDevice, f->stream));
+    for (int w = 0; w < 3; w++)
+        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
+    HIPC(f, hipEventRecord(f->ev0, f->stream));
+    for (int r = 0; r < reps; r++)
+        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
+    HIPC(f, hipEventRecord(f->ev1, f->stream));
+    HIPC(f, hipEventSynchronize(f->ev1));
+    float ms = 0;
+    HIPC(f, hipEventElapsedTime(&ms, f->ev0, f->ev1));
+    *mean_us = 1e3 * ms / reps;
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dC);
+    return EKFVIO_OK;
+}
+
 int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
                                float* L_out, float* X_out, int32_t* info) {
-    // S: m x m (ld m) SPD; Crhs: nrhs x m (ld nrhs); L_out m x m; X_out = Crhs * S^-1 (nrhs x m)
+    // S: m x m (ld m) SPD; Crhs: nrhs x m (ld nrhs); L_out m x m; X_out = Crhs * S^-1 (nrhs x m).
+    // Runs the production path: augmented sweep + gain GEMMs.
     if (!f || m <= 0 || nrhs <= 0 || !S || !Crhs) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
     const int mp = round_up(m, 64), rp = round_up(nrhs, 64);
-    float *dS, *dL, *dLi, *dX, *dW;
-    HIPC(f, dev_alloc(f->stream, &dS, (size_t)mp * mp));
-    HIPC(f, dev_alloc(f->stream, &dL, (size_t)mp * mp));
+    const int ld = mp + rp + mp;
+    std::vector<float> hs((size_t)ld * mp, 0.f);
+    for (int c = 0; c < mp; c++) {
+        for (int r = 0; r < mp; r++) hs[(size_t)c * ld + r] = (r < m && c < m) ? S[(size_t)c * m + r] : (r == c ? 1.f : 0.f);
+        if (c < m)
+            for (int r = 0; r < nrhs; r++) hs[(size_t)c * ld + mp + r] = Crhs[(size_t)c * nrhs + r];
+        hs[(size_t)c * ld + mp + rp + c] = 1.f;
+    }
+    float *dS, *dL, *dLi, *dK, *dW;
+    HIPC(f, dev_alloc(f->stream, &dS, hs.size()));
+    HIPC(f, dev_alloc(f->stream, &dL, hs.size()));
     HIPC(f, dev_alloc(f->stream, &dLi, (size_t)64 * mp));
-    HIPC(f, dev_alloc(f->stream, &dX, (size_t)rp * mp));
+    HIPC(f, dev_alloc(f->stream, &dK, (size_t)rp * mp));
     HIPC(f, dev_alloc(f->stream, &dW, (size_t)rp * mp));
-    std::vector<float> hs((size_t)mp * mp, 0.f);
-    for (int c = 0; c < mp; c++)
-        for (int r = 0; r < mp; r++) hs[(size_t)c * mp + r] = (r < m && c < m) ? S[(size_t)c * m + r] : (r == c ? 1.f : 0.f);
     HIPC(f, hipMemcpyAsync(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, f->stream));
-    HIPC(f, hipMemcpy2DAsync(dX, sizeof(float) * rp, Crhs, sizeof(float) * nrhs, sizeof(float) * nrhs, m,
-                             hipMemcpyHostToDevice, f->stream));
-    launch_cholesky(f, dS, dL, dLi, mp, mp);
-    launch_solve_right(f, dL, dLi, mp, mp, dX, dW, nrhs, rp);
-    if (L_out) HIPC(f, hipMemcpy2DAsync(L_out, sizeof(float) * m, dL, sizeof(float) * mp, sizeof(float) * m, m,
-                                        hipMemcpyDeviceToHost, f->stream));
-    if (X_out) HIPC(f, hipMemcpy2DAsync(X_out, sizeof(float) * nrhs, dX, sizeof(float) * rp, sizeof(float) * nrhs, m,
-                                        hipMemcpyDeviceToHost, f->stream));
+    launch_chol_sweep(f, dS, dL, dLi, mp, rp, ld);
+    launch_gain_from_sweep(f, dL, mp, rp, ld, nrhs, dK, dW, rp, 1);
+    std::vector<float> hl(hs.size()), hk((size_t)rp * mp);
+    HIPC(f, hipMemcpyAsync(hl.data(), dL, sizeof(float) * hl.size(), hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipMemcpyAsync(hk.data(), dK, sizeof(float) * hk.size(), hipMemcpyDeviceToHost, f->stream));
     if (info) {
         HIPC(f, hipMemcpyAsync(info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
         HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
     }
     HIPC(f, hipStreamSynchronize(f->stream));
+    if (L_out)
+        for (int c = 0; c < m; c++)
+            for (int r = 0; r < m; r++) L_out[(size_t)c * m + r] = (r >= c) ? hl[(size_t)c * ld + r] : 0.f;
+    if (X_out)
+        for (int c = 0; c < m; c++)
+            for (int r = 0; r < nrhs; r++) X_out[(size_t)c * nrhs + r] = hk[(size_t)c * rp + r];
     hipFree(dS);
     hipFree(dL);
     hipFree(dLi);
-    hipFree(dX);
+    hipFree(dK);
     hipFree(dW);
     return EKFVIO_OK;
 }

@@ -10,8 +10,10 @@
 //     A_ij -= L_ik L_jk^T, and the workgroup that owns the next diagonal tile (k+1,k+1)
 //     immediately factors it in LDS (look-ahead), so the sequential chain is one launch per
 //     block step.
-//   K = ((Sigma H^T) L^-T) L^-1 by two blocked substitutions, again one launch per block
-//     step (diagonal-block solve + trailing update fused).
+//   The sweep runs over the augmented matrix [A; Sigma H^T; I]: the extra row blocks are
+//     just more tiles of the same launches (the forward substitution Y L^T = X IS the
+//     panel/trailing step), so it also delivers Y = Sigma H^T L^-T and L^-T.  The gain is
+//     then K = Y L^-1 as MFMA GEMMs (gemm.hip) with one residual-refinement step.
 //
 // Triangular solves against a 64x64 diagonal block are micro-blocked substitutions with
 // 16-wide blocks: each wavefront owns 16 rows of the right-hand side in LDS and alternates
@@ -130,25 +132,6 @@ __device__ inline void tri_solve_fwd(float* Tx, const float* Tl, const float* Ti
         }
     }
 }
-// X <- X L^-1 (descending micro-blocks)
-__device__ inline void tri_solve_bwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
-    const int r0 = 16 * wave, li = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int p = 3; p >= 0; p--) {
-        // K_p(i,j) = sum_q X(r0+i, 16p+q) Inv_p(q,j)
-        const f32x4 y = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tinv + p * 16 * ILD, ILD, 1, lane);
-#pragma unroll
-        for (int g = 0; g < 4; g++) Tx[(16 * p + 4 * lk + g) * PLD + r0 + li] = y[g];
-#pragma unroll
-        for (int t = 0; t < p; t++) {
-            // X(r0+i, 16t+j) -= sum_q K_p(i,q) L(16p+q, 16t+j)
-            const f32x4 u = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tl + 16 * t * PLD + 16 * p, PLD, 1, lane);
-#pragma unroll
-            for (int g = 0; g < 4; g++) Tx[(16 * t + 4 * lk + g) * PLD + r0 + li] -= u[g];
-        }
-    }
-}
-
 // ---- 64x64 Cholesky inside one workgroup ------------------------------------------------
 // A: LDS tile holding (at least) the lower triangle of an SPD block; on return its lower
 // triangle is L and the strict upper triangle is zero.  Tinv receives the fp32-rounded
@@ -250,20 +233,32 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
     if (bad && tid == 0) atomicOr(info, 1);
 }
 
-// Block step k of the right-looking sweep; grid.x = r(r+1)/2 tiles, r = mb-1-k.
+// Block step k of the right-looking sweep over the augmented matrix [A; X; I].
+// grid.x = r(r+1)/2 triangular tiles of A (r = mb-1-k) + rb*r rectangular tiles of the extra
+// row blocks (X: the forward substitution Y L^T = X rides along; I: yields L^-T).
+// idb0 = first identity row block: its block row q is still zero left of column block q.
 __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
-                                                        float* __restrict__ Linv, int k, int* info) {
+                                                        float* __restrict__ Linv, int k, int mb, int idb0, int* info) {
     __shared__ float Ti[PB * PLD];   // A_ik, then L_ik
     __shared__ float Tj[PB * PLD];   // A_jk, then L_jk
     __shared__ float Tl[PB * PLD];   // L_kk, later the updated next diagonal tile
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
-    // decode the lower-triangular tile index: t = ii(ii+1)/2 + jj, 0 <= jj <= ii
-    int t = blockIdx.x, ii = 0;
-    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-    const int jj = t - ii * (ii + 1) / 2;
-    const int i = k + 1 + ii, j = k + 1 + jj;
+    const int rr = mb - 1 - k, ntri = rr * (rr + 1) / 2;
+    int t = blockIdx.x, i, j;
+    if (t < ntri) {
+        // lower-triangular tile index: t = ii(ii+1)/2 + jj, 0 <= jj <= ii
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+        i = k + 1 + ii;
+        j = k + 1 + (t - ii * (ii + 1) / 2);
+    } else {
+        t -= ntri;
+        i = mb + t / rr;
+        j = k + 1 + t % rr;
+        if (i >= idb0 && i - idb0 > k) return;  // identity block row: block (i,k) is still zero
+    }
 
     load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
     load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
@@ -300,97 +295,53 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
 }
 
-// Forward sweep step k of  Y L^T = X  (X: nrows x m_pad, ld ldx):  grid (slabs, mb-k).
-//   blockIdx.y == 0      : Y_k = X_k L_kk^-T                 -> W_k
-//   blockIdx.y == jj > 0 : X_j -= (X_k L_kk^-T) L_jk^T,  j = k + jj
-__global__ __launch_bounds__(256) void solve_fwd_kernel(float* __restrict__ X, float* __restrict__ W, int ldx,
-                                                        const float* __restrict__ L, int ldl,
-                                                        const float* __restrict__ Linv, int k) {
-    __shared__ float Tx[PB * PLD];
+// X_k <- X_k L_kk^-T for the extra row blocks at the last block column (no trailing tiles left)
+__global__ __launch_bounds__(256) void chol_last_panel_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
+                                                              int ldl, const float* __restrict__ Linv, int k, int mb) {
+    __shared__ float Ti[PB * PLD];
     __shared__ float Tl[PB * PLD];
-    __shared__ float Tp[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave & 1, wc = wave >> 1;
-    const int slab = blockIdx.x, jj = blockIdx.y, j = k + jj;
-    load_tile(Tx, X + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
+    const int i = mb + blockIdx.x;
     load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
     load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
-    if (jj > 0) load_tile(Tp, L + (size_t)k * PB * ldl + (size_t)j * PB, ldl, tid);
+    load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
     __syncthreads();
-    tri_solve_fwd(Tx, Tl, Tinv, wave, lane);
+    tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
     __syncthreads();
-    if (jj == 0) {
-        store_tile(Tx, W + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
-        return;
-    }
-    // X_j(r,s) -= sum_c Y(r,c) L_jk(s,c)
-    const f32x16 up = mma64(Tx, 1, PLD, Tp, 1, PLD, wr, wc, lane);
-    float* Xj = X + (size_t)j * PB * ldx + (size_t)slab * PB;
-    const int r = wr * 32 + (lane & 31);
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        Xj[(size_t)c * ldx + r] -= up[q];
-    }
-}
-
-// Backward sweep step k of  K L = Y  (Y in W, K written to X):  grid (slabs, k+1).
-//   blockIdx.y == 0      : K_k = W_k L_kk^-1                 -> X_k
-//   blockIdx.y == jj > 0 : W_j -= (W_k L_kk^-1) L_kj,  j = jj - 1
-__global__ __launch_bounds__(256) void solve_bwd_kernel(float* __restrict__ X, float* __restrict__ W, int ldx,
-                                                        const float* __restrict__ L, int ldl,
-                                                        const float* __restrict__ Linv, int k) {
-    __shared__ float Tx[PB * PLD];
-    __shared__ float Tl[PB * PLD];
-    __shared__ float Tp[PB * PLD];
-    __shared__ float Tinv[INV_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave & 1, wc = wave >> 1;
-    const int slab = blockIdx.x, jj = blockIdx.y, j = jj - 1;
-    load_tile(Tx, W + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
-    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
-    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
-    if (jj > 0) load_tile(Tp, L + (size_t)j * PB * ldl + (size_t)k * PB, ldl, tid);
-    __syncthreads();
-    tri_solve_bwd(Tx, Tl, Tinv, wave, lane);
-    __syncthreads();
-    if (jj == 0) {
-        store_tile(Tx, X + (size_t)k * PB * ldx + (size_t)slab * PB, ldx, tid);
-        return;
-    }
-    // W_j(r,s) -= sum_q K(r,q) L_kj(q,s):  B(j=s,q) = L_kj(q,s) at s*PLD + q
-    const f32x16 up = mma64(Tx, 1, PLD, Tp, PLD, 1, wr, wc, lane);
-    float* Wj = W + (size_t)j * PB * ldx + (size_t)slab * PB;
-    const int r = wr * 32 + (lane & 31);
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        Wj[(size_t)c * ldx + r] -= up[q];
-    }
+    store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
 }
 
 }  // namespace
 
-void launch_cholesky(ekfvio_filter* f, float* S, float* L, float* Linv, int m_pad, int lds) {
-    ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0);
+void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld) {
+    ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad);
     const int mb = m_pad / PB;
-    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, S, lds, L, lds, Linv, f->info);
+    const int rb = n_pad / PB + mb;        // extra row blocks: X then I
+    const int idb0 = mb + n_pad / PB;
+    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info);
     for (int k = 0; k + 1 < mb; k++) {
         const int r = mb - 1 - k;
-        hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2), dim3(256), 0, f->stream, S, lds, L, lds, Linv, k,
-                           f->info);
+        hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2 + rb * r), dim3(256), 0, f->stream, Saug, ld, Laug, ld,
+                           Linv, k, mb, idb0, f->info);
     }
+    hipLaunchKernelGGL(chol_last_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb);
 }
 
-// X <- X * A^-1 with A = L L^T; X is nrows x m_pad (ld = ldx, rows padded to 64), W scratch.
-void launch_solve_right(ekfvio_filter* f, const float* L, const float* Linv, int m_pad, int lds, float* X, float* W,
-                        int nrows, int ldx) {
-    ProfScope ps(f, PC_SOLVE, 2.0 * nrows * (double)m_pad * m_pad);
-    const int mb = m_pad / PB;
-    const int slabs = (nrows + PB - 1) / PB;
-    for (int k = 0; k < mb; k++)
-        hipLaunchKernelGGL(solve_fwd_kernel, dim3(slabs, mb - k), dim3(256), 0, f->stream, X, W, ldx, L, lds, Linv, k);
-    for (int k = mb - 1; k >= 0; k--)
-        hipLaunchKernelGGL(solve_bwd_kernel, dim3(slabs, k + 1), dim3(256), 0, f->stream, X, W, ldx, L, lds, Linv, k);
+// K = X A^-1 = Y L^-1 with Y = X L^-T and L^-T (both from the sweep): one MFMA GEMM that
+// skips the structurally zero part of the triangular operand and prunes like sparseView
+// (:580).  refine != 0 adds one step of residual refinement against L itself,
+// K <- K + (Y - K L) L^-1 (two more GEMMs); on the filter's matrices it changes nothing
+// measurable (the error is dominated by the fp32 factor itself), so it is off by default.
+void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
+                            float* scratch, int ldk, int refine) {
+    ProfScope ps(f, PC_SOLVE, (refine ? 3.0 : 1.0) * n * (double)m_pad * m_pad);
+    const float* Lf = Laug;
+    const float* Y = Laug + m_pad;
+    const float* LinvT = Laug + m_pad + n_pad;
+    launch_gemm(f->stream, 1, n, m_pad, m_pad, 1.f, Y, ld, LinvT, ld, 0.f, nullptr, 0, K, ldk, refine ? 0 : 1, 1);
+    if (refine) {
+        launch_gemm(f->stream, 0, n, m_pad, m_pad, -1.f, K, ldk, Lf, ld, 1.f, Y, ld, scratch, ldk, 0, 1);     // Y - K L
+        launch_gemm(f->stream, 1, n, m_pad, m_pad, 1.f, scratch, ldk, LinvT, ld, 1.f, K, ldk, K, ldk, 1, 1);  // + prune
+    }
 }

@@ -80,9 +80,14 @@ struct ekfvio_filter {
     uint8_t* pass = nullptr;   // [max_features]
     float* yres = nullptr;     // [m_cap] residual
     float* Rm = nullptr;       // [m_cap*2] per measurement row r: R(r,r) and the off-diagonal partner
-    float* S = nullptr;        // [m_cap*m_cap]
-    float* L = nullptr;        // [m_cap*m_cap] Cholesky factor (lower)
-    float* Linv = nullptr;     // [64*m_cap] inverses of the diagonal blocks of L
+    // Augmented sweep matrices, ld_aug x m_cap, column-major.  Row blocks of Saug:
+    //   [0, m_pad)                 A = (H Sigma H^T + R)^T           -> Laug: L (Cholesky factor)
+    //   [m_pad, m_pad+n_pad)       Sigma H^T                         -> Laug: Y = Sigma H^T L^-T
+    //   [m_pad+n_pad, +m_pad)      identity                          -> Laug: L^-T
+    float* Saug = nullptr;
+    float* Laug = nullptr;
+    int ld_aug = 0;            // m_cap + ldp + m_cap
+    float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
     float* Km = nullptr;       // [ldp*m_cap]  Sigma H^T, solved in place into the Kalman gain
     float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
     float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
@@ -116,21 +121,27 @@ struct ekfvio_filter {
 
 // ---- launchers implemented across the translation units -------------------------------
 // C[MxN] = beta*Cin + alpha * A[MxK] * op(B); all column-major.  transB: B is [NxK]
-// (op = transpose) else [KxN].  K must be a multiple of 16 and the K-padding of both
+// (op = transpose) else [KxN].  K must be a multiple of 32 and the K-padding of both
 // operands finite*0-safe (zero).  flush != 0 applies the reference's prune (|x|<=1e-13 -> 0).
 void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush);
+                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB = 0);
+
+// same, selecting a tile configuration (0 = production default chosen by shape)
+void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                         const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
+                         int lowerB);
 
 void launch_linearize(ekfvio_filter* f, float dt);
 void launch_build_dense_F(ekfvio_filter* f, float* Fdense);
 void launch_predict(ekfvio_filter* f, float dt);
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass);
 void launch_check_sigma(ekfvio_filter* f, float* d_out);
-// Cholesky of S (m_pad x m_pad, ld = lds; lower) into L, diagonal-block inverses into Linv,
-// then X <- X * S^-1 for the nrows x m_pad matrix X (ld = ldx) in place; W is scratch of the same shape.
-void launch_cholesky(ekfvio_filter* f, float* S, float* L, float* Linv, int m_pad, int lds);
-void launch_solve_right(ekfvio_filter* f, const float* L, const float* Linv, int m_pad, int lds, float* X, float* W,
-                        int nrows, int ldx);
+// Augmented blocked Cholesky sweep (chol.hip): Saug = [A; X; I] (row blocks of 64; A is
+// m_pad x m_pad, X has n_pad rows) -> Laug = [L; X L^-T; L^-T], both ld x m_pad column-major.
+void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld);
+// K = X A^-1 (n rows, ldk) from the sweep output: K = Y L^-1 (+ optional residual refinement).
+void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
+                            float* scratch, int ldk, int refine);
 
 int klt_alloc(ekfvio_filter* f);  // klt.hip
 void klt_free(ekfvio_filter* f);

@@ -9,6 +9,9 @@
 // in the reference's operation order (including the places where a double literal makes the
 // reference compute in double), so the Jacobian blocks and propagated means agree with an
 // x86-64 build of the same formulas to the last bit wherever the math library does.
+#include <algorithm>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -370,48 +373,37 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
 // A(r,c) = S(c,r) so that the Cholesky kernels (which read the lower triangle) factor the
 // same numbers as the reference.  C = Sigma H^T (columns of Sigma); Wt = (H Sigma)^T (rows
 // of Sigma, transposed so that it is state-major).
-__global__ __launch_bounds__(256) void gather_S_kernel(const float* __restrict__ P, int ld, const int* __restrict__ idx,
-                                                       const float* __restrict__ Rm, int m, int m_pad, float* S,
-                                                       int lds) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
-    if (r >= m_pad) return;
-    float v;
-    if (r < m && c < m) {
-        v = P[(size_t)idx[r] * ld + idx[c]];  // Sigma(idx[c], idx[r]) = S(c,r)
-        if (r == c)
-            v = v + Rm[2 * r];
-        else if ((r ^ 1) == c)
-            v = v + Rm[2 * r + 1];  // R(c,r): the off-diagonal element of column r
-    } else {
-        v = (r == c) ? 1.f : 0.f;
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P, int ld, int n,
+                                                     const int* __restrict__ idx, const float* __restrict__ Rm, int m,
+                                                     int m_pad, int n_pad, float* Saug, int lda, float* Wt) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;  // measurement column
+    const int sc = (c < m) ? idx[c] : 0;
+    if (x < m_pad) {
+        const int r = x;
+        float v;
+        if (r < m && c < m) {
+            v = P[(size_t)idx[r] * ld + sc];  // Sigma(idx[c], idx[r]) = S(c,r)
+            if (r == c)
+                v = v + Rm[2 * r];
+            else if ((r ^ 1) == c)
+                v = v + Rm[2 * r + 1];  // R(c,r): the off-diagonal element of column r
+        } else {
+            v = (r == c) ? 1.f : 0.f;
+        }
+        Saug[(size_t)c * lda + r] = v;
+        Saug[(size_t)c * lda + m_pad + n_pad + r] = (r == c) ? 1.f : 0.f;  // identity block
     }
-    S[(size_t)c * lds + r] = v;
-}
-
-__global__ __launch_bounds__(256) void gather_CW_kernel(const float* __restrict__ P, int ld, int n,
-                                                        const int* __restrict__ idx, int m, int m_pad, float* C,
-                                                        float* Wt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (i >= ld) return;
-    float c = 0.f, w = 0.f;
-    if (r < m && i < n) {
-        const int s = idx[r];
-        c = P[(size_t)s * ld + i];   // Sigma(i, idx[r])
-        w = P[(size_t)i * ld + s];   // Sigma(idx[r], i)
+    if (x < ld) {
+        const int i = x;
+        float cv = 0.f, w = 0.f;
+        if (c < m && i < n) {
+            cv = P[(size_t)sc * ld + i];  // Sigma(i, idx[c])
+            w = P[(size_t)i * ld + sc];   // Sigma(idx[c], i)
+        }
+        if (i < n_pad) Saug[(size_t)c * lda + m_pad + i] = cv;
+        Wt[(size_t)c * ld + i] = w;
     }
-    C[(size_t)r * ld + i] = c;
-    Wt[(size_t)r * ld + i] = w;
-}
-
-// K <- prune(K) (sparseView :580) on the logical n x m block
-__global__ void flush_kernel(float* K, int ld, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (i >= n) return;
-    float v = K[(size_t)r * ld + i];
-    if (!(fabsf(v) > EKF_FLUSH_THRESH)) K[(size_t)r * ld + i] = 0.f;
 }
 
 // G = K*R - T[:, idx]   (so that Sigma' = T + G*K^T = T*I_KH^T + K*R*K^T, :594-596)
@@ -517,7 +509,7 @@ void launch_predict(ekfvio_filter* f, float dt) {
     dim3 grid((n + 255) / 256, n);
     if (f->cfg.predict_mode == EKFVIO_PREDICT_DENSE) {
         launch_build_dense_F(f, f->Fdense);
-        const int np = round_up(n, 16);
+        const int np = round_up(n, 32);
         {
             ProfScope ps(f, PC_GEMM_PREDICT, 4.0 * n * (double)n * n);
             // X = F*P (B = P is [K x N]); P' = X*F^T (B = F is [N x K])
@@ -533,33 +525,29 @@ void launch_predict(ekfvio_filter* f, float dt) {
                            f->P);
     }
     // the propagated mean becomes the state (landmarks used the OLD base state, :102-107)
-    hipMemcpyAsync(f->mu, f->mu_next, sizeof(float) * f->n, hipMemcpyDeviceToDevice, f->stream);
+    std::swap(f->mu, f->mu_next);
 }
 
 // updateWithFeaturePositions (:475-628) on device-resident z/R/pass; m = 2*(#passed) known to the host
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass) {
     const int n = f->n, ld = f->ldp, N = f->N;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
-    const int lds = f->m_cap;
+    const int n_pad = round_up(n, EKF_TILE);
+    const int lda = f->ld_aug;
     {
         ProfScope ps(f, PC_GATHER);
         hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, N, m_pad, d_z, d_R, d_pass,
                            f->mu, f->last_klt, f->del_flag, f->idx, f->yres, f->Rm);
         if (m > 0) {
-            hipLaunchKernelGGL(gather_S_kernel, dim3((m_pad + 255) / 256, m_pad), dim3(256), 0, f->stream, f->P, ld,
-                               f->idx, f->Rm, m, m_pad, f->S, lds);
-            hipLaunchKernelGGL(gather_CW_kernel, dim3((ld + 255) / 256, m_pad), dim3(256), 0, f->stream, f->P, ld, n,
-                               f->idx, m, m_pad, f->Km, f->Wt);
+            const int gx = (std::max(ld, m_pad) + 255) / 256;
+            hipLaunchKernelGGL(gather_kernel, dim3(gx, m_pad), dim3(256), 0, f->stream, f->P, ld, n, f->idx, f->Rm, m,
+                               m_pad, n_pad, f->Saug, lda, f->Wt);
         }
     }
     if (m > 0) {
-        launch_cholesky(f, f->S, f->L, f->Linv, m_pad, lds);
-        // K = (Sigma H^T) S^-1  (:577-580), in place in Km; Gm is scratch until form_G
-        launch_solve_right(f, f->L, f->Linv, m_pad, lds, f->Km, f->Gm, n, ld);
-        {
-            ProfScope ps(f, PC_UPDATE_MISC);
-            hipLaunchKernelGGL(flush_kernel, dim3((n + 255) / 256, m), dim3(256), 0, f->stream, f->Km, ld, n);
-        }
+        // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
+        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda);
+        launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
         {
             // T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place
             ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);

@@ -163,6 +163,9 @@ int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t*
 /* Raw kernels for unit tests (column-major, device copies made internally). */
 int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
                      int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc);
+/* Mean time (us) of `reps` back-to-back GEMM launches at one shape, operands resident. */
+int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int32_t M, int32_t N, int32_t K,
+                           int32_t reps, int32_t variant, double* mean_us);
 int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
                                float* L_out, float* X_out, int32_t* info);
 
