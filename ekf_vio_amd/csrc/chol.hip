@@ -37,17 +37,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ILD 17  // stride of a 16x16 inverse block in LDS
 #define INV_LDS (4 * 16 * ILD)
 
-__device__ inline float lane_bcast(float v, int src_lane) {
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
-__device__ inline double lane_bcast_d(double v, int src_lane) {
+__device__ __forceinline__ double lane_bcast_d(double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
 
 // ---- tile movers (256 threads) ---------------------------------------------------------
-__device__ inline void load_tile(float* T, const float* __restrict__ G, int ld, int tid) {
+__device__ __forceinline__ void load_tile(float* T, const float* __restrict__ G, int ld, int tid) {
     // 64x64 column-major global tile -> LDS (c*PLD + r); 16-byte global loads along r
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -58,7 +58,7 @@ __device__ inline void load_tile(float* T, const float* __restrict__ G, int ld, 
         t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     }
 }
-__device__ inline void store_tile(const float* T, float* __restrict__ G, int ld, int tid) {
+__device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G, int ld, int tid) {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int e = tid + it * 256;
@@ -68,13 +68,13 @@ __device__ inline void store_tile(const float* T, float* __restrict__ G, int ld,
     }
 }
 // four 16x16 inverse blocks (global: block p at p*256, column-major ld 16) <-> LDS (stride ILD)
-__device__ inline void load_inv(float* Tinv, const float* __restrict__ G, int tid) {
+__device__ __forceinline__ void load_inv(float* Tinv, const float* __restrict__ G, int tid) {
     const float4 v = *reinterpret_cast<const float4*>(G + tid * 4);
     const int p = tid >> 6, c = (tid >> 2) & 15, r4 = (tid & 3) * 4;
     float* t = Tinv + p * 16 * ILD + c * ILD + r4;
     t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
 }
-__device__ inline void store_inv(const float* Tinv, float* __restrict__ G, int tid) {
+__device__ __forceinline__ void store_inv(const float* Tinv, float* __restrict__ G, int tid) {
     const int p = tid >> 6, c = (tid >> 2) & 15, r4 = (tid & 3) * 4;
     const float* t = Tinv + p * 16 * ILD + c * ILD + r4;
     *reinterpret_cast<float4*>(G + tid * 4) = make_float4(t[0], t[1], t[2], t[3]);
@@ -84,7 +84,7 @@ __device__ inline void store_inv(const float* Tinv, float* __restrict__ G, int t
 // B(j,q) at Bs[j*b_sj + q*b_sq].  Operands are passed swapped so that the accumulator's
 // lane index runs along i:
 //   acc[reg] <-> (i = wr*32 + lane%32, j = wc*32 + (reg&3) + 8*(reg>>2) + 4*(lane/32)).
-__device__ inline f32x16 mma64(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int wr, int wc,
+__device__ __forceinline__ f32x16 mma64(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int wr, int wc,
                                int lane) {
     f32x16 acc;
 #pragma unroll
@@ -102,7 +102,7 @@ __device__ inline f32x16 mma64(const float* As, int a_si, int a_sq, const float*
 }
 
 // 16x16 tile: acc[reg] <-> (i = lane%16, j = 4*(lane/16) + reg);  acc = sum_{q<16} A(i,q)*B(j,q)
-__device__ inline f32x4 mma16(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int lane) {
+__device__ __forceinline__ f32x4 mma16(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int lane) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lk = lane >> 4;
     const float* ap = As + li * a_si + lk * a_sq;
@@ -115,7 +115,7 @@ __device__ inline f32x4 mma16(const float* As, int a_si, int a_sq, const float* 
 // X <- X L^-T for a 64x64 tile X (Tx) against the lower-triangular 64x64 block in Tl, given
 // the inverses of its four 16x16 diagonal blocks (Tinv).  Wavefront w owns rows 16w..16w+15;
 // no barrier inside.
-__device__ inline void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
+__device__ __forceinline__ void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
     const int r0 = 16 * wave, li = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -142,11 +142,16 @@ __device__ inline void tri_solve_fwd(float* Tx, const float* Tl, const float* Ti
 // the pivot column over all 64 lanes IS the panel's triangular solve, so no barrier or LDS
 // round trip sits on the pivot chain.  The trailing update runs on 16x16x4 MFMA tiles
 // spread over the four wavefronts.
-__device__ inline bool potrf64_lds(float* A, float* Tinv, int tid) {
+#define POTRF_STAMP(i)                                                         \
+    do {                                                                       \
+        if (stamps && tid == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+__device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long long* stamps = nullptr) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     bool bad = false;
+    POTRF_STAMP(1);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int c0 = 16 * p;
@@ -161,8 +166,7 @@ __device__ inline bool potrf64_lds(float* A, float* Tinv, int tid) {
                     bad = true;
                     d = 1e-20f;
                 }
-                float inv = __builtin_amdgcn_rsqf(d);
-                inv = inv * (1.5f - 0.5f * d * inv * inv);  // one Newton step: ~correctly rounded
+                const float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, <= 1 ulp
                 const float lkk = d * inv;
                 a[k] = (lane == c0 + k) ? lkk : a[k] * inv;
 #pragma unroll
@@ -177,6 +181,7 @@ __device__ inline bool potrf64_lds(float* A, float* Tinv, int tid) {
             }
         }
         __syncthreads();
+        POTRF_STAMP(2 + 2 * p);
         // trailing update on the 16x16 tiles (ti >= tj > p): A(r,s) -= sum_q P(r,q) P(s,q)
         const int nt = 3 - p;               // tiles per side
         const int ntile = nt * (nt + 1) / 2;
@@ -190,33 +195,58 @@ __device__ inline bool potrf64_lds(float* A, float* Tinv, int tid) {
             for (int g = 0; g < 4; g++) A[(cb + 4 * lk + g) * PLD + rb + li] -= u[g];
         }
         __syncthreads();
+        POTRF_STAMP(3 + 2 * p);
     }
     // zero the strict upper triangle (the tile may have carried the symmetric upper part)
     for (int e = tid; e < PB * PB; e += 256) {
         const int r = e % PB, c = e / PB;
         if (r < c) A[c * PLD + r] = 0.f;
     }
-    // inverse of diagonal block `wave` in fp64: lane c < 16 owns column c of the inverse
+    // (no barrier needed: the inverse only uses entries on or below the diagonal)
+    // Inverse of the 16x16 diagonal block `wave` (four blocks, four wavefronts in parallel) by
+    // forward substitution in registers: lane r (< 16) holds row r of the block, lane c owns
+    // column c of the inverse, L(r,q) reaches every lane through v_readlane.  fp32 is enough
+    // for 16x16 blocks (measured against fp64-formed inverses: no difference in the filter
+    // state; the 64x64 inverses tried first did need fp64).
     {
         const int o = 16 * wave;
-        const double dinv_own = 1.0 / (double)A[(o + li) * PLD + o + li];
-        double acc[16], x[16];
+        float lrow[16], acc[16], x[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = (r == li) ? 1.0 : 0.0;
+        for (int q = 0; q < 16; q++) lrow[q] = A[(o + q) * PLD + o + li];  // L(o+li, o+q)
+        const float dinv_own = 1.0f / A[(o + li) * PLD + o + li];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = (r == li) ? 1.f : 0.f;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const double xq = acc[q] * lane_bcast_d(dinv_own, q);
+            const float xq = acc[q] * lane_bcast(dinv_own, q);
             x[q] = xq;
 #pragma unroll
-            for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fma(-(double)A[(o + q) * PLD + o + r], xq, acc[r]);
+            for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fmaf(-lane_bcast(lrow[q], r), xq, acc[r]);
         }
         if (lane < 16) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) Tinv[wave * 16 * ILD + li * ILD + r] = (float)x[r];
+            for (int r = 0; r < 16; r++) Tinv[wave * 16 * ILD + li * ILD + r] = x[r];
         }
     }
     __syncthreads();
+    POTRF_STAMP(10);
     return bad;
+}
+
+// Diagnostic twin of potrf64_kernel: same work, s_memtime stamps after every phase.
+__global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
+                                                            int ldl, float* __restrict__ Linv, long long* stamps) {
+    __shared__ float A[PB * PLD];
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x;
+    if (tid == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime();
+    load_tile(A, S, lds, tid);
+    __syncthreads();
+    potrf64_lds(A, Tinv, tid, stamps);
+    store_tile(A, L, ldl, tid);
+    store_inv(Tinv, Linv, tid);
+    __syncthreads();
+    if (tid == 0) stamps[11] = (long long)__builtin_amdgcn_s_memtime();
 }
 
 // Factor the first diagonal block (step "-1" of the sweep).
@@ -313,6 +343,10 @@ __global__ __launch_bounds__(256) void chol_last_panel_kernel(const float* __res
 }
 
 }  // namespace
+
+void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps) {
+    hipLaunchKernelGGL(potrf64_stamp_kernel, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps);
+}
 
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld) {
     ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad);

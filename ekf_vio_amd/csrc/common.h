@@ -113,6 +113,15 @@ struct ekfvio_filter {
     double t_stamp = 0;
     bool have_stamp = false;
 
+    // --- hipGraph replay of device-resident sequences (two steps per graph: the mean
+    //     ping-pong mu <-> mu_next is back in its starting orientation after an even count) ---
+    hipGraphExec_t step_graph = nullptr;
+    int graph_N = -1, graph_m = -1, graph_frames = -1;
+    float graph_dt = -1.f;
+    float* graph_mu = nullptr;      // orientation of the mean buffers at capture time
+    const void* graph_seq = nullptr;
+    int use_graph = 1;
+
     // --- profiler ---
     bool prof_on = false;
     ProfSlot prof[PC_COUNT];
@@ -134,11 +143,13 @@ void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, i
 void launch_linearize(ekfvio_filter* f, float dt);
 void launch_build_dense_F(ekfvio_filter* f, float* Fdense);
 void launch_predict(ekfvio_filter* f, float dt);
-void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass);
+void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass,
+                   int* d_frame_counter = nullptr, int frames = 0);
 void launch_check_sigma(ekfvio_filter* f, float* d_out);
 // Augmented blocked Cholesky sweep (chol.hip): Saug = [A; X; I] (row blocks of 64; A is
 // m_pad x m_pad, X has n_pad rows) -> Laug = [L; X L^-T; L^-T], both ld x m_pad column-major.
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld);
+void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);
 // K = X A^-1 (n rows, ldk) from the sweep output: K = Y L^-1 (+ optional residual refinement).
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
                             float* scratch, int ldk, int refine);

@@ -311,14 +311,23 @@ __global__ void add_noise_flush_kernel(float* P, int ld, int n, float dt) {
 // measurement map idx (formFeatureMeasurementMap :634-661), stores last_klt / delete flags,
 // z - H*mu and the per-row measurement noise.  Integer work is bit-exact by construction.
 // ---------------------------------------------------------------------------------------
+// With a frame counter (device-resident sequences replayed from a hipGraph) the measurement
+// of frame *frame_counter is used and the counter advances modulo `frames`.
 __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_pad, const float* __restrict__ z,
                                                                   const float* __restrict__ R,
                                                                   const uint8_t* __restrict__ pass,
                                                                   const float* __restrict__ mu, float* last_klt,
-                                                                  uint8_t* del_flag, int* idx, float* yres, float* Rm) {
+                                                                  uint8_t* del_flag, int* idx, float* yres, float* Rm,
+                                                                  int* frame_counter, int frames) {
     __shared__ int s_cnt[1024];
     __shared__ int s_total;
     const int tid = threadIdx.x;
+    if (frame_counter) {
+        const int fi = *frame_counter;
+        z += (size_t)fi * 2 * N;
+        R += (size_t)fi * 4 * N;
+        pass += (size_t)fi * N;
+    }
     const int per = (N + 1023) / 1024;
     const int lo = tid * per;
     const int hi = min(N, lo + per);
@@ -363,6 +372,10 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
         yres[r] = 0.f;
         Rm[2 * r] = 0.f;
         Rm[2 * r + 1] = 0.f;
+    }
+    if (frame_counter && tid == 0) {  // every thread read the counter before the first barrier
+        const int fi = *frame_counter + 1;
+        *frame_counter = (fi >= frames) ? 0 : fi;
     }
 }
 
@@ -529,7 +542,8 @@ void launch_predict(ekfvio_filter* f, float dt) {
 }
 
 // updateWithFeaturePositions (:475-628) on device-resident z/R/pass; m = 2*(#passed) known to the host
-void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass) {
+void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, int* d_frame_counter,
+                   int frames) {
     const int n = f->n, ld = f->ldp, N = f->N;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     const int n_pad = round_up(n, EKF_TILE);
@@ -537,7 +551,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     {
         ProfScope ps(f, PC_GATHER);
         hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, N, m_pad, d_z, d_R, d_pass,
-                           f->mu, f->last_klt, f->del_flag, f->idx, f->yres, f->Rm);
+                           f->mu, f->last_klt, f->del_flag, f->idx, f->yres, f->Rm, d_frame_counter, frames);
         if (m > 0) {
             const int gx = (std::max(ld, m_pad) + 255) / 256;
             hipLaunchKernelGGL(gather_kernel, dim3(gx, m_pad), dim3(256), 0, f->stream, f->P, ld, n, f->idx, f->Rm, m,
