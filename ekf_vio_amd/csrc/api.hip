@@ -518,6 +518,18 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
     float ms = 0;
     HIPC(f, hipEventElapsedTime(&ms, f->ev0, f->ev1));
     *mean_us = 1e3 * ms / reps;
+    if (variant >= 10) {  // diagnostic (library built with -DEKF_GEMM_STAMPS): one stamped launch (tile (1,1)), stamps returned through mean_us[1..40]
+        long long* dst;
+        HIPC(f, dev_alloc(f->stream, &dst, 40));
+        gemm_set_stamp_buffer(dst);
+        launch_gemm_variant(f->stream, variant - 10, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
+        long long hst[40];
+        HIPC(f, hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, f->stream));
+        HIPC(f, hipStreamSynchronize(f->stream));
+        gemm_set_stamp_buffer(nullptr);
+        for (int i = 0; i < 40; i++) mean_us[1 + i] = (double)hst[i];
+        hipFree(dst);
+    }
     hipFree(dA);
     hipFree(dB);
     hipFree(dC);

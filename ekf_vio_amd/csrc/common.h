@@ -140,6 +140,8 @@ void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, i
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                          int lowerB);
 
+void gemm_set_stamp_buffer(long long* d_buf);  // diagnostics: nullptr disables
+
 void launch_linearize(ekfvio_filter* f, float dt);
 void launch_build_dense_F(ekfvio_filter* f, float* Fdense);
 void launch_predict(ekfvio_filter* f, float dt);

@@ -23,6 +23,17 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Diagnostic cycle stamps (s_memtime) of workgroup (0,0), wave 0; nullptr in production.
+__device__ long long* g_gemm_stamps = nullptr;
+#ifdef EKF_GEMM_STAMPS  // build with -DEKF_GEMM_STAMPS for scripts/gemm_stamps.py
+#define GSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        if (stamps_ && (i) < 40) stamps_[i] = (long long)__builtin_amdgcn_s_memtime();             \
+    } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 #define BM 64
 #define BN 64
 #define BK 32
@@ -30,16 +41,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_BT (BN)      // transB: [BK][BN], written with b128
 #define LDS_BN (BN + 1)  // !transB: [BK][BN+1], written transposed with b32 (conflict-free)
 
-template <bool TRANSB>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
+// GROUPS = 2: 512 threads; wavefronts 4-7 run the same pipeline on the second half of the
+// K-tiles out of their own LDS buffers (two waves per SIMD fill each other's issue bubbles),
+// and the two accumulators are summed through LDS before the epilogue.
+template <bool TRANSB, int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                             int lda, const float* __restrict__ B, int ldb, float beta,
                                                             const float* Cin, int ldcin, float* C, int ldc, int flush,
                                                             int lowerB) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDS_A];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDS_BN];
+    __shared__ __attribute__((aligned(16))) float AsG[GROUPS][2][BK * LDS_A];
+    __shared__ __attribute__((aligned(16))) float BsG[GROUPS][2][BK * LDS_BN];
     constexpr int LDB_S = TRANSB ? LDS_BT : LDS_BN;
 
-    const int tid = threadIdx.x;
+#ifdef EKF_GEMM_STAMPS
+    long long* stamps_ = (blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) ? g_gemm_stamps : nullptr;
+#endif
+    GSTAMP(0);
+    const int grp = (GROUPS > 1) ? (threadIdx.x >> 8) : 0;
+    float (*As)[BK * LDS_A] = AsG[grp];
+    float (*Bs)[BK * LDS_BN] = BsG[grp];
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave & 1;   // 32-row half of the tile
@@ -56,8 +77,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(int M, int N, int K,
 
     // lowerB: op(B)(k,j) is zero for k < j (B is L, or L^-T stored row-wise): start the
     // contraction at this tile's first column
-    const int kbeg = lowerB ? min(j0, K) : 0;
-    const int KT = (K - kbeg) / BK;
+    const int kbeg0 = lowerB ? min(j0, K) : 0;
+    const int KTall = (K - kbeg0) / BK;
+    const int KTm = (KTall + GROUPS - 1) / GROUPS;                 // iterations every group runs (barrier count)
+    const int KT = max(0, min(KTm, KTall - grp * KTm));           // K-tiles this group really has
+    const int kbeg = kbeg0 + grp * KTm * BK;
     const float* Ap = A + (size_t)(kbeg + a_k) * lda + i0 + a_i;
     const float* Bp = TRANSB ? (B + (size_t)(kbeg + a_k) * ldb + j0 + a_i) : (B + (size_t)(j0 + b_j) * ldb + kbeg + b_k);
     const size_t a_step = (size_t)BK * lda, b_step = TRANSB ? (size_t)BK * ldb : (size_t)BK;
@@ -133,14 +157,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(int M, int N, int K,
 #define GEMM_MFMA1(S, kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S##b[kk], S##a[kk], acc, 0, 0, 0)
     // one K-tile: MFMAs from set C; fragments of the next tile -> set Nx from LDS[nb];
     // staging registers -> LDS[sb]; global loads of tile `lt`.  fr/stg/ld switch the stages on.
-#define GEMM_TILE(C, Nx, nb, sb, fr, stg, ld, lt)                                              \
+#define GEMM_TILE(C, Nx, nb, sb, act, fr, stg, ld, lt)                                         \
     do {                                                                                       \
         const float* as_ = &As[nb][lk * LDS_A + wr * 32 + li];                                 \
         const float* bs_ = &Bs[nb][lk * LDB_S + wc * 32 + li];                                 \
         const float* ap_ = Ap + (size_t)(lt) * a_step;                                         \
         const float* bp_ = Bp + (size_t)(lt) * b_step;                                         \
         _Pragma("unroll") for (int sl = 0; sl < 16; sl++) {                                    \
-            GEMM_MFMA1(C, sl);                                                                 \
+            if (act) GEMM_MFMA1(C, sl);                                                        \
             if (sl < 8 && (fr)) {                                                              \
                 Nx##a[2 * sl] = as_[(4 * sl) * LDS_A];                                         \
                 Nx##a[2 * sl + 1] = as_[(4 * sl + 2) * LDS_A];                                 \
@@ -163,30 +187,69 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(int M, int N, int K,
         }                                                                                      \
     } while (0)
 
-    // prologue: tile 0 staged and its fragments read; tile 1 staged; tile 2 in flight
-    if (KT > 0) {
-        GEMM_LOAD(0);
-        GEMM_STAGE(0);
+    // The C tile this wave will update is requested first: vmcnt retires in order, so these
+    // loads ride in front of the prologue's own round trip instead of stalling the first
+    // staging wait of the K loop.
+    const int ci_ = i0 + wr * 32 + li;
+    float cpre[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int j = j0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        cpre[r] = (beta != 0.f && ci_ < M && j < N) ? Cin[(size_t)j * ldcin + ci_] : 0.f;
     }
-    if (KT > 1) GEMM_LOAD(1);
-    __syncthreads();
-    if (KT > 0) GEMM_FRAGS(F, 0);
-    if (KT > 1) GEMM_STAGE(1);
-    if (KT > 2) GEMM_LOAD(2);
-    __syncthreads();
+    // prologue: tiles 0 and 1 are requested together (one memory round trip); tile 0 staged
+    // and its fragments read; tile 1 staged; tile 2 in flight
+    {
+        float4 ya0, ya1, yb0, yb1;
+        ya0 = ya1 = yb0 = yb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KT > 0) GEMM_LOAD(0);
+        if (KT > 1) {
+            const float* ap_ = Ap + a_step;
+            const float* bp_ = Bp + b_step;
+            ya0 = *reinterpret_cast<const float4*>(ap_);
+            ya1 = *reinterpret_cast<const float4*>(ap_ + a_half);
+            yb0 = *reinterpret_cast<const float4*>(bp_);
+            yb1 = *reinterpret_cast<const float4*>(bp_ + b_half);
+        }
+        if (KT > 0) GEMM_STAGE(0);
+        __syncthreads();
+        if (KT > 0) GEMM_FRAGS(F, 0);
+        xa0 = ya0; xa1 = ya1; xb0 = yb0; xb1 = yb1;
+        if (KT > 1) GEMM_STAGE(1);
+        if (KT > 2) GEMM_LOAD(2);
+        __syncthreads();
+    }
+    GSTAMP(1);
+    // Every K-tile runs the same fully active body: beyond the last tile the prefetch index
+    // is clamped (a redundant reload of the last tile) and what gets staged / read as
+    // fragments is never consumed, so the loop needs no per-stage conditions.
+    const int klast = KT > 0 ? KT - 1 : 0;
+    const bool any = KT > 0;  // a group without tiles touches no memory
     int kt = 0;
-    for (; kt + 4 < KT; kt += 2) {  // steady state: every stage active for both tiles
-        GEMM_TILE(F, G, 1, 0, true, true, true, kt + 3);
+    for (; kt + 1 < KTm; kt += 2) {
+        GEMM_TILE(F, G, 1, 0, kt < KT, any, any, any, min(kt + 3, klast));
         __syncthreads();
-        GEMM_TILE(G, F, 0, 1, true, true, true, kt + 4);
+        GSTAMP(2 + kt);
+        GEMM_TILE(G, F, 0, 1, kt + 1 < KT, any, any, any, min(kt + 4, klast));
+        __syncthreads();
+        GSTAMP(3 + kt);
+    }
+    if (kt < KTm) {  // odd tile count
+        GEMM_TILE(F, G, 1, 0, kt < KT, false, false, false, klast);
         __syncthreads();
     }
-    for (; kt < KT; kt += 2) {  // tail: stages switch off as the tiles run out
-        GEMM_TILE(F, G, 1, 0, kt + 1 < KT, kt + 2 < KT, kt + 3 < KT, kt + 3);
+    GSTAMP(36);
+    if (GROUPS > 1) {
+        // sum the groups' accumulators through LDS (group 0's staging buffers are free now)
+        float* red = &AsG[0][0][0];
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[r * 256 + tid] = acc[r];
+        }
         __syncthreads();
-        if (kt + 1 >= KT) break;
-        GEMM_TILE(G, F, 0, 1, kt + 2 < KT, kt + 3 < KT, kt + 4 < KT, kt + 4);
-        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] += red[r * 256 + tid];
     }
 #undef GEMM_LOAD
 #undef GEMM_STAGE
@@ -198,37 +261,66 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(int M, int N, int K,
 #undef GEMM_MFMA1
 #undef GEMM_TILE
 
-    // epilogue: lane -> row i (contiguous), register -> column j
+    GSTAMP(37);
+    // epilogue: lane -> row i (contiguous), register -> column j.  All 16 outputs are formed
+    // first; interior tiles then store without per-element tests.
     const int i = i0 + wr * 32 + li;
-    if (i < M) {
+    float vout[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float v = alpha * acc[r];
+        v = v + beta * cpre[r];
+        if (flush) v = (fabsf(v) > EKF_FLUSH_THRESH) ? v : 0.f;
+        vout[r] = v;
+    }
+    float* cp = C + (size_t)(j0 + wc * 32 + 4 * lk) * ldc + i;
+    if (i0 + BM <= M && j0 + BN <= N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = vout[r];
+    } else if (i < M) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int j = j0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (j < N) {
-                float v = alpha * acc[r];
-                if (beta != 0.f) v += beta * Cin[(size_t)j * ldcin + i];
-                if (flush && !(fabsf(v) > EKF_FLUSH_THRESH)) v = 0.f;
-                C[(size_t)j * ldc + i] = v;
-            }
+            const int jo = (r & 3) + 8 * (r >> 2);
+            if (j0 + wc * 32 + 4 * lk + jo < N) cp[(size_t)jo * ldc] = vout[r];
         }
     }
+    GSTAMP(38);
 }
 
-void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB) {
+static void launch_gemm_cfg(hipStream_t s, int groups, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                            const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
+                            int lowerB) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    if (transB)
-        hipLaunchKernelGGL(gemm_f32_mfma_kernel<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, Cin,
-                           ldcin, C, ldc, flush, lowerB);
-    else
-        hipLaunchKernelGGL(gemm_f32_mfma_kernel<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
-                           Cin, ldcin, C, ldc, flush, lowerB);
+#define GEMM_GO(TB, G)                                                                                              \
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
+                       Cin, ldcin, C, ldc, flush, lowerB)
+    if (groups == 2) {
+        if (transB) GEMM_GO(true, 2);
+        else GEMM_GO(false, 2);
+    } else {
+        if (transB) GEMM_GO(true, 1);
+        else GEMM_GO(false, 1);
+    }
+#undef GEMM_GO
+}
+
+// Production configuration: 256 threads.  (GROUPS = 2 is kept for the micro-benchmark.)
+void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    (void)tiles;
+    const int groups = 1;  // the 8-wavefront variant measured slower at every shape tried (profiles/)
+    launch_gemm_cfg(s, groups, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
 }
 
 void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                          int lowerB) {
-    (void)variant;
-    launch_gemm(s, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
+    if (variant == 0)
+        launch_gemm(s, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
+    else
+        launch_gemm_cfg(s, variant, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
 }
+
+void gemm_set_stamp_buffer(long long* d_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &d_buf, sizeof(d_buf)); }
