@@ -106,7 +106,7 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     }
     const int maxf = cfg->max_features;
     f->n_cap = EKF_BASE + 3 * maxf;
-    f->ldp = round_up(f->n_cap, 64);
+    f->ldp = round_up(f->n_cap + 1, 64);  // one spare row/column: the K*y column of the Joseph-1 GEMM
     f->m_cap = round_up(2 * maxf > 0 ? 2 * maxf : 1, 64);
     const size_t pp = (size_t)f->ldp * f->ldp, pm = (size_t)f->ldp * f->m_cap;
     HIPC(f, dev_alloc(f->stream, &f->mu, f->ldp));
@@ -120,6 +120,7 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     HIPC(f, dev_alloc(f->stream, &f->FD, 9 * (size_t)maxf));
     HIPC(f, dev_alloc(f->stream, &f->Fdense, pp));
     HIPC(f, dev_alloc(f->stream, &f->idx, (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->inv_idx, (size_t)f->ldp));
     HIPC(f, dev_alloc(f->stream, &f->zmeas, 2 * (size_t)maxf));
     HIPC(f, dev_alloc(f->stream, &f->Rmeas, 4 * (size_t)maxf));
     HIPC(f, dev_alloc(f->stream, &f->pass, (size_t)maxf));
@@ -146,7 +147,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     hipSetDevice(f->device);
     hipStreamSynchronize(f->stream);
     void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
-                    f->idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km,
+                    f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km,
                     f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
     for (void* p : ptrs)
         if (p) hipFree(p);

@@ -75,6 +75,7 @@ struct ekfvio_filter {
     float* Fdense = nullptr;   // [ldp*ldp] only in dense predict mode / ekfvio_linearize
     // --- update work ---
     int* idx = nullptr;        // [m_cap] state index of measurement row r
+    int* inv_idx = nullptr;    // [ldp]   measurement row of state index j, or -1
     float* zmeas = nullptr;    // [2*max_features] device copy of z
     float* Rmeas = nullptr;    // [4*max_features]
     uint8_t* pass = nullptr;   // [max_features]
@@ -132,8 +133,28 @@ struct ekfvio_filter {
 // C[MxN] = beta*Cin + alpha * A[MxK] * op(B); all column-major.  transB: B is [NxK]
 // (op = transpose) else [KxN].  K must be a multiple of 32 and the K-padding of both
 // operands finite*0-safe (zero).  flush != 0 applies the reference's prune (|x|<=1e-13 -> 0).
+// Filter-specific epilogues of the two Joseph GEMMs (mode 0 = none):
+//  mode 1  T = Sigma - K (H Sigma): besides T, writes G = K R - T[:, idx] for the measured
+//          columns (inv_idx: state index -> measurement row or -1) so that no separate pass
+//          re-reads T; the residual rides as an extra row of (H Sigma)^T, so output column n
+//          receives K*y.
+//  mode 2  Sigma' = T + G K^T: workgroup (0,0) also finishes the mean: mu += column n,
+//          quaternion renormalised (:600-609), column n zeroed again, frame counter advanced.
+struct GemmEpi {
+    int mode = 0;
+    const int* inv_idx = nullptr;
+    const float* Rm = nullptr;
+    float* G = nullptr;
+    int ldg = 0;
+    float* mu = nullptr;
+    float* Pcol = nullptr;  // column n of P
+    int n = 0;
+    int* frame_counter = nullptr;
+    int frames = 0;
+};
 void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB = 0);
+                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB = 0,
+                 const GemmEpi* epi = nullptr);
 
 // same, selecting a tile configuration (0 = production default chosen by shape)
 void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,

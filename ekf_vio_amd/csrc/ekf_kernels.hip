@@ -317,8 +317,8 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
                                                                   const float* __restrict__ R,
                                                                   const uint8_t* __restrict__ pass,
                                                                   const float* __restrict__ mu, float* last_klt,
-                                                                  uint8_t* del_flag, int* idx, float* yres, float* Rm,
-                                                                  int* frame_counter, int frames) {
+                                                                  uint8_t* del_flag, int* idx, int* inv_idx, float* yres,
+                                                                  float* Rm, const int* frame_counter) {
     __shared__ int s_cnt[1024];
     __shared__ int s_total;
     const int tid = threadIdx.x;
@@ -360,9 +360,13 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
             Rm[2 * r + 1] = R[4 * i + 1];
             Rm[2 * r + 2] = R[4 * i + 3];
             Rm[2 * r + 3] = R[4 * i + 2];
+            inv_idx[s] = r;
+            inv_idx[s + 1] = r + 1;
+            inv_idx[s + 2] = -1;
             base++;
         } else {
             del_flag[i] = 1;
+            inv_idx[EKF_BASE + 3 * i] = inv_idx[EKF_BASE + 3 * i + 1] = inv_idx[EKF_BASE + 3 * i + 2] = -1;
         }
     }
     __syncthreads();
@@ -373,10 +377,7 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
         Rm[2 * r] = 0.f;
         Rm[2 * r + 1] = 0.f;
     }
-    if (frame_counter && tid == 0) {  // every thread read the counter before the first barrier
-        const int fi = *frame_counter + 1;
-        *frame_counter = (fi >= frames) ? 0 : fi;
-    }
+    if (tid <= EKF_BASE) inv_idx[tid == EKF_BASE ? EKF_BASE + 3 * N : tid] = -1;  // base state and the K*y column
 }
 
 // A = (H Sigma H^T + R)^T (:559-561, :578), padded with the identity.  The reference hands
@@ -388,7 +389,8 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
 // of Sigma, transposed so that it is state-major).
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P, int ld, int n,
                                                      const int* __restrict__ idx, const float* __restrict__ Rm, int m,
-                                                     int m_pad, int n_pad, float* Saug, int lda, float* Wt) {
+                                                     int m_pad, int n_pad, float* Saug, int lda, float* Wt,
+                                                     const float* __restrict__ yres, float* G) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;  // measurement column
     const int sc = (c < m) ? idx[c] : 0;
@@ -415,38 +417,20 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P
             w = P[(size_t)i * ld + sc];   // Sigma(idx[c], i)
         }
         if (i < n_pad) Saug[(size_t)c * lda + m_pad + i] = cv;
+        if (i == n) w = (c < m) ? -yres[c] : 0.f;  // extra row: the Joseph-1 GEMM then yields K*y in column n
         Wt[(size_t)c * ld + i] = w;
+        if (c >= m) G[(size_t)c * ld + i] = 0.f;   // padding columns of G stay zero
     }
 }
 
-// G = K*R - T[:, idx]   (so that Sigma' = T + G*K^T = T*I_KH^T + K*R*K^T, :594-596)
-__global__ __launch_bounds__(256) void form_G_kernel(const float* __restrict__ K, const float* __restrict__ T, int ld,
-                                                     int n, const int* __restrict__ idx, const float* __restrict__ Rm,
-                                                     int m, float* G) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (i >= ld) return;
-    float g = 0.f;
-    if (r < m && i < n) {
-        const int p = r ^ 1;  // partner row of the same landmark
-        // (K R)(i,r) = K(i,r) R(r,r) + K(i,p) R(p,r); ascending measurement index like the reference
-        const float rrr = Rm[2 * r];
-        const float rpr = Rm[2 * r + 1];  // R(p,r): the off-diagonal element of column r
-        float kr;
-        if (p < r)
-            kr = K[(size_t)p * ld + i] * rpr + K[(size_t)r * ld + i] * rrr;
-        else
-            kr = K[(size_t)r * ld + i] * rrr + K[(size_t)p * ld + i] * rpr;
-        g = kr - T[(size_t)idx[r] * ld + i];
-    }
-    G[(size_t)r * ld + i] = g;
-}
-
+// (G = K*R - T[:, idx] and mu += K*y are epilogues of the two Joseph GEMMs: see GemmEpi.)
+// Stand-alone mean update, used when no landmark was measured (m = 0):
 // mu += K*y (:600), quaternion renormalisation (:605-609).  64 state rows per workgroup;
 // the four wavefronts each sum a quarter of the measurement rows (coalesced along the state
 // index), combined in ascending order.
 __global__ __launch_bounds__(256) void mean_update_kernel(const float* __restrict__ K, int ld, int n, int m,
-                                                          const float* __restrict__ y, float* mu) {
+                                                          const float* __restrict__ y, float* mu, int* frame_counter,
+                                                          int frames) {
     __shared__ float s_part[4][64];
     __shared__ float s_q[4];
     const int rl = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -471,6 +455,10 @@ __global__ __launch_bounds__(256) void mean_update_kernel(const float* __restric
         }
     }
     if (w == 0 && i < n) mu[i] = v;
+    if (frame_counter && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int fi = *frame_counter + 1;
+        *frame_counter = (fi >= frames) ? 0 : fi;
+    }
 }
 
 __global__ void check_sigma_kernel(const float* P, int ld, int n, float* out) {
@@ -551,37 +539,45 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     {
         ProfScope ps(f, PC_GATHER);
         hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, N, m_pad, d_z, d_R, d_pass,
-                           f->mu, f->last_klt, f->del_flag, f->idx, f->yres, f->Rm, d_frame_counter, frames);
+                           f->mu, f->last_klt, f->del_flag, f->idx, f->inv_idx, f->yres, f->Rm, d_frame_counter);
         if (m > 0) {
             const int gx = (std::max(ld, m_pad) + 255) / 256;
             hipLaunchKernelGGL(gather_kernel, dim3(gx, m_pad), dim3(256), 0, f->stream, f->P, ld, n, f->idx, f->Rm, m,
-                               m_pad, n_pad, f->Saug, lda, f->Wt);
+                               m_pad, n_pad, f->Saug, lda, f->Wt, f->yres, f->Gm);
         }
     }
+    GemmEpi e2;
+    e2.mode = 2;
+    e2.mu = f->mu;
+    e2.Pcol = f->P + (size_t)n * ld;
+    e2.n = n;
+    e2.frame_counter = d_frame_counter;
+    e2.frames = frames;
     if (m > 0) {
         // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
         launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda);
         launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
         {
-            // T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place
+            // T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place; also G and K*y (column n)
             ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);
-            launch_gemm(f->stream, 1, n, n, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0);
+            GemmEpi e1;
+            e1.mode = 1;
+            e1.inv_idx = f->inv_idx;
+            e1.Rm = f->Rm;
+            e1.G = f->Gm;
+            e1.ldg = ld;
+            launch_gemm(f->stream, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
         }
         {
-            ProfScope ps(f, PC_UPDATE_MISC);
-            hipLaunchKernelGGL(form_G_kernel, dim3((ld + 255) / 256, m_pad), dim3(256), 0, f->stream, f->Km, f->P, ld, n,
-                               f->idx, f->Rm, m, f->Gm);
-        }
-        {
-            // Sigma' = T + G*K^T, pruned (:594-596, :625)
+            // Sigma' = T + G*K^T, pruned (:594-596, :625); workgroup (0,0) finishes the mean
             ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);
-            launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1);
+            launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
         }
-    }
-    {
+    } else {
+        // no measurement: products are empty, only the quaternion renormalisation remains (:605-609)
         ProfScope ps(f, PC_UPDATE_MISC);
-        hipLaunchKernelGGL(mean_update_kernel, dim3((n + 63) / 64), dim3(256), 0, f->stream, f->Km, ld, n, m, f->yres,
-                           f->mu);
+        hipLaunchKernelGGL(mean_update_kernel, dim3((n + 63) / 64), dim3(256), 0, f->stream, f->Km, ld, n, 0, f->yres, f->mu,
+                           d_frame_counter, frames);
     }
 }
 

@@ -44,11 +44,11 @@ __device__ long long* g_gemm_stamps = nullptr;
 // GROUPS = 2: 512 threads; wavefronts 4-7 run the same pipeline on the second half of the
 // K-tiles out of their own LDS buffers (two waves per SIMD fill each other's issue bubbles),
 // and the two accumulators are summed through LDS before the epilogue.
-template <bool TRANSB, int GROUPS>
+template <bool TRANSB, int GROUPS, int EPI>
 __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                             int lda, const float* __restrict__ B, int ldb, float beta,
                                                             const float* Cin, int ldcin, float* C, int ldc, int flush,
-                                                            int lowerB) {
+                                                            int lowerB, GemmEpi epi) {
     __shared__ __attribute__((aligned(16))) float AsG[GROUPS][2][BK * LDS_A];
     __shared__ __attribute__((aligned(16))) float BsG[GROUPS][2][BK * LDS_BN];
     constexpr int LDB_S = TRANSB ? LDS_BT : LDS_BN;
@@ -273,6 +273,51 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
         if (flush) v = (fabsf(v) > EKF_FLUSH_THRESH) ? v : 0.f;
         vout[r] = v;
     }
+    if (EPI == 1) {
+        // G(i,q) = (K R)(i,q) - T(i, idx[q]) for the measured columns of this tile (A is K).
+        // All loads are unconditional on clamped indices (so they are issued as one batch);
+        // only the store is predicated.
+        const int ic = min(i, M - 1);
+        int qv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = j0 + wc * 32 + 4 * lk + (r & 3) + 8 * (r >> 2);
+            qv[r] = epi.inv_idx[min(j, N - 1)];
+        }
+        float kq[16], kp[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int q = max(qv[r], 0);
+            kq[r] = A[(size_t)q * lda + ic] * epi.Rm[2 * q];
+            kp[r] = A[(size_t)(q ^ 1) * lda + ic] * epi.Rm[2 * q + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = j0 + wc * 32 + 4 * lk + (r & 3) + 8 * (r >> 2);
+            const int q = qv[r];
+            const float kr = ((q ^ 1) < q) ? (kp[r] + kq[r]) : (kq[r] + kp[r]);  // ascending measurement index
+            if (q >= 0 && j < N && i < M) epi.G[(size_t)q * epi.ldg + i] = kr - vout[r];
+        }
+    }
+    if (EPI == 2 && blockIdx.x == 0 && blockIdx.y == 0) {
+        // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
+        __shared__ float s_q[4];
+        for (int e = threadIdx.x; e < epi.n; e += 256 * GROUPS) {
+            const float v = epi.mu[e] + epi.Pcol[e];
+            if (e >= 3 && e <= 6) s_q[e - 3] = v;
+            else epi.mu[e] = v;
+            epi.Pcol[e] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
+            epi.mu[3 + threadIdx.x] = s_q[threadIdx.x] / qn;
+        }
+        if (threadIdx.x == 0 && epi.frame_counter) {
+            const int fi = *epi.frame_counter + 1;
+            *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
+        }
+    }
     float* cp = C + (size_t)(j0 + wc * 32 + 4 * lk) * ldc + i;
     if (i0 + BM <= M && j0 + BN <= N) {
 #pragma unroll
@@ -289,38 +334,40 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
 
 static void launch_gemm_cfg(hipStream_t s, int groups, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                             const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
-                            int lowerB) {
+                            int lowerB, const GemmEpi* epi) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-#define GEMM_GO(TB, G)                                                                                              \
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
-                       Cin, ldcin, C, ldc, flush, lowerB)
-    if (groups == 2) {
-        if (transB) GEMM_GO(true, 2);
-        else GEMM_GO(false, 2);
+    GemmEpi e;
+    if (epi) e = *epi;
+#define GEMM_GO(TB, G, EP)                                                                                             \
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G, EP>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
+                       Cin, ldcin, C, ldc, flush, lowerB, e)
+    if (e.mode == 1) {
+        GEMM_GO(true, 1, 1);  // the Joseph GEMMs are always A * B^T
+    } else if (e.mode == 2) {
+        GEMM_GO(true, 1, 2);
+    } else if (groups == 2) {
+        if (transB) GEMM_GO(true, 2, 0);
+        else GEMM_GO(false, 2, 0);
     } else {
-        if (transB) GEMM_GO(true, 1);
-        else GEMM_GO(false, 1);
+        if (transB) GEMM_GO(true, 1, 0);
+        else GEMM_GO(false, 1, 0);
     }
 #undef GEMM_GO
 }
 
 // Production configuration: 256 threads.  (GROUPS = 2 is kept for the micro-benchmark.)
 void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB) {
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    (void)tiles;
-    const int groups = 1;  // the 8-wavefront variant measured slower at every shape tried (profiles/)
-    launch_gemm_cfg(s, groups, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
+                 int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB,
+                 const GemmEpi* epi) {
+    launch_gemm_cfg(s, 1, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, epi);
 }
 
 void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                          int lowerB) {
-    if (variant == 0)
-        launch_gemm(s, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
-    else
-        launch_gemm_cfg(s, variant, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB);
+    launch_gemm_cfg(s, variant == 2 ? 2 : 1, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB,
+                    nullptr);
 }
 
 void gemm_set_stamp_buffer(long long* d_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &d_buf, sizeof(d_buf)); }
