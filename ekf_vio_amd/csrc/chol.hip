@@ -132,29 +132,67 @@ __device__ __forceinline__ void tri_solve_fwd(float* Tx, const float* Tl, const 
         }
     }
 }
-// ---- 64x64 Cholesky inside one workgroup ------------------------------------------------
-// A: LDS tile holding (at least) the lower triangle of an SPD block; on return its lower
-// triangle is L and the strict upper triangle is zero.  Tinv receives the fp32-rounded
-// inverses of the four 16x16 diagonal blocks of L.  Returns true if a pivot was <= 0.
-//
-// Four 16-column micro-panels.  Wavefront 0 holds one matrix row per lane (16 panel
-// entries in registers) and runs the 16 pivot steps with v_readlane broadcasts: scaling
-// the pivot column over all 64 lanes IS the panel's triangular solve, so no barrier or LDS
-// round trip sits on the pivot chain.  The trailing update runs on 16x16x4 MFMA tiles
-// spread over the four wavefronts.
 #define POTRF_STAMP(i)                                                         \
     do {                                                                       \
         if (stamps && tid == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+
+// ---- 64x64 Cholesky inside one workgroup ------------------------------------------------
+// A: LDS tile holding (at least) the lower triangle of an SPD block; on return its lower
+// triangle is L and the strict upper triangle is zero.  Tinv receives the inverses of the
+// four 16x16 diagonal blocks of L.  Returns true if a pivot was <= 0.
+//
+// Four 16-column micro-panels.  Only the pivot chain is serial: wavefront 0 holds one matrix
+// row per lane (16 panel entries in registers) and runs the 16 pivot steps with v_readlane
+// broadcasts; scaling the pivot column over all 64 lanes IS the panel's triangular solve,
+// so no barrier or LDS round trip sits on the chain.  Schedule per panel p:
+//   phase F: wave 0 factors panel p   ||  waves 1-3 finish the trailing update of panel p-1
+//            (the tiles right of the next panel) and invert diagonal block p-1;
+//   phase C: the tiles that make up panel p+1's columns get panel p's update (<= 3 tiles).
+// Trailing tiles are 16x16 MFMA tiles (v_mfma_f32_16x16x4_f32).
+__device__ __forceinline__ void potrf_tile_update(float* A, int c0, int ti, int tj, int lane) {
+    // A(rb.., cb..) -= P(rb.., c0..c0+15) P(cb.., c0..c0+15)^T
+    const int li = lane & 15, lk = lane >> 4;
+    const int rb = c0 + 16 + 16 * ti, cb = c0 + 16 + 16 * tj;
+    const f32x4 u = mma16(A + c0 * PLD + rb, 1, PLD, A + c0 * PLD + cb, 1, PLD, lane);
+#pragma unroll
+    for (int g = 0; g < 4; g++) A[(cb + 4 * lk + g) * PLD + rb + li] -= u[g];
+}
+
+// Inverse of the 16x16 diagonal block b by forward substitution in registers: lane r (< 16)
+// holds row r of the block, lane c owns column c of the inverse, L(r,q) reaches every lane
+// through v_readlane.  fp32 is enough for 16x16 blocks (measured against fp64-formed
+// inverses: no difference in the filter state; 64x64 inverses did need fp64).
+__device__ __forceinline__ void potrf_inverse16(const float* A, float* Tinv, int b, int lane) {
+    const int o = 16 * b, li = lane & 15;
+    float lrow[16], acc[16], x[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) lrow[q] = A[(o + q) * PLD + o + li];  // L(o+li, o+q)
+    const float dinv_own = 1.0f / A[(o + li) * PLD + o + li];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = (r == li) ? 1.f : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const float xq = acc[q] * lane_bcast(dinv_own, q);
+        x[q] = xq;
+#pragma unroll
+        for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fmaf(-lane_bcast(lrow[q], r), xq, acc[r]);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) Tinv[b * 16 * ILD + li * ILD + r] = x[r];
+    }
+}
+
 __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long long* stamps = nullptr) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
     bool bad = false;
     POTRF_STAMP(1);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int c0 = 16 * p;
+        // ---- phase F ----
         if (wave == 0) {
             float a[16];
 #pragma unroll
@@ -179,53 +217,37 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
 #pragma unroll
                 for (int j = 0; j < 16; j++) A[(c0 + j) * PLD + lane] = (lane - c0 >= j) ? a[j] : 0.f;
             }
+        } else if (p == 1) {
+            // rest of panel 0's trailing update: tiles (1,1) | (2,1),(2,2); wave 1 inverts block 0
+            if (wave == 1) potrf_inverse16(A, Tinv, 0, lane);
+            if (wave == 2) potrf_tile_update(A, 0, 1, 1, lane);
+            if (wave == 3) {
+                potrf_tile_update(A, 0, 2, 1, lane);
+                potrf_tile_update(A, 0, 2, 2, lane);
+            }
+        } else if (p == 2) {
+            if (wave == 1) potrf_tile_update(A, 16, 1, 1, lane);
+            if (wave == 2) potrf_inverse16(A, Tinv, 1, lane);
+        } else if (p == 3) {
+            if (wave == 3) potrf_inverse16(A, Tinv, 2, lane);
         }
         __syncthreads();
         POTRF_STAMP(2 + 2 * p);
-        // trailing update on the 16x16 tiles (ti >= tj > p): A(r,s) -= sum_q P(r,q) P(s,q)
-        const int nt = 3 - p;               // tiles per side
-        const int ntile = nt * (nt + 1) / 2;
-        for (int t = wave; t < ntile; t += 4) {
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-            const int tj = t - ti * (ti + 1) / 2;
-            const int rb = c0 + 16 + 16 * ti, cb = c0 + 16 + 16 * tj;
-            const f32x4 u = mma16(A + c0 * PLD + rb, 1, PLD, A + c0 * PLD + cb, 1, PLD, lane);
-#pragma unroll
-            for (int g = 0; g < 4; g++) A[(cb + 4 * lk + g) * PLD + rb + li] -= u[g];
+        // ---- phase C: panel p's update of the next panel's columns (tiles (ti,0)) ----
+        if (p < 3) {
+            if (wave < 3 - p) potrf_tile_update(A, c0, wave, 0, lane);
+            __syncthreads();
         }
-        __syncthreads();
         POTRF_STAMP(3 + 2 * p);
     }
-    // zero the strict upper triangle (the tile may have carried the symmetric upper part)
-    for (int e = tid; e < PB * PB; e += 256) {
-        const int r = e % PB, c = e / PB;
-        if (r < c) A[c * PLD + r] = 0.f;
-    }
-    // (no barrier needed: the inverse only uses entries on or below the diagonal)
-    // Inverse of the 16x16 diagonal block `wave` (four blocks, four wavefronts in parallel) by
-    // forward substitution in registers: lane r (< 16) holds row r of the block, lane c owns
-    // column c of the inverse, L(r,q) reaches every lane through v_readlane.  fp32 is enough
-    // for 16x16 blocks (measured against fp64-formed inverses: no difference in the filter
-    // state; the 64x64 inverses tried first did need fp64).
-    {
-        const int o = 16 * wave;
-        float lrow[16], acc[16], x[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) lrow[q] = A[(o + q) * PLD + o + li];  // L(o+li, o+q)
-        const float dinv_own = 1.0f / A[(o + li) * PLD + o + li];
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = (r == li) ? 1.f : 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const float xq = acc[q] * lane_bcast(dinv_own, q);
-            x[q] = xq;
-#pragma unroll
-            for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fmaf(-lane_bcast(lrow[q], r), xq, acc[r]);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) Tinv[wave * 16 * ILD + li * ILD + r] = x[r];
+    // zero the strict upper triangle (the tile may have carried the symmetric upper part);
+    // wave 0 inverts the last diagonal block meanwhile (it only reads on/below the diagonal)
+    if (wave == 0) {
+        potrf_inverse16(A, Tinv, 3, lane);
+    } else {
+        for (int e = tid - 64; e < PB * PB; e += 192) {
+            const int r = e % PB, c = e / PB;
+            if (r < c) A[c * PLD + r] = 0.f;
         }
     }
     __syncthreads();
