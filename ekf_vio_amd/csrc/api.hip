@@ -169,6 +169,7 @@ int ekfvio_reset(ekfvio_filter* f) {
     f->N = 0;
     f->n = EKF_BASE;
     HIPC(f, hipMemsetAsync(f->P, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
+    HIPC(f, hipMemsetAsync(f->P2, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));  // ping-pong partner: padding must be zero
     HIPC(f, hipMemsetAsync(f->mu, 0, sizeof(float) * f->ldp, f->stream));
     const float one = 1.f;
     HIPC(f, hipMemcpyAsync(f->mu + 3, &one, sizeof(float), hipMemcpyHostToDevice, f->stream));
@@ -323,6 +324,7 @@ int ekfvio_set_state(ekfvio_filter* f, int32_t N, const float* base_mu, const fl
     if (ld < n || (N > 0 && (!mu3N || !last_klt2N || !delN))) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
     HIPC(f, hipMemsetAsync(f->P, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
+    HIPC(f, hipMemsetAsync(f->P2, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
     HIPC(f, hipMemsetAsync(f->mu, 0, sizeof(float) * f->ldp, f->stream));
     HIPC(f, hipMemcpyAsync(f->mu, base_mu, sizeof(float) * EKF_BASE, hipMemcpyHostToDevice, f->stream));
     if (N > 0) {
@@ -386,7 +388,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
         int* counter = f->info + 1;
         f->h_info[1] = first % f->seq_frames;
         HIPC(f, hipMemcpyAsync(counter, &f->h_info[1], sizeof(int), hipMemcpyHostToDevice, f->stream));
-        if (!f->step_graph || f->graph_N != f->N || f->graph_m != m || f->graph_dt != dt || f->graph_mu != f->mu ||
+        if (!f->step_graph || f->graph_N != f->N || f->graph_m != m || f->graph_dt != dt || f->graph_mu != f->mu || f->graph_P != f->P ||
             f->graph_seq != f->seq_z || f->graph_frames != f->seq_frames) {
             drop_graph(f);
             hipGraph_t g = nullptr;
@@ -403,7 +405,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
             }
             HIPC(f, hipGraphInstantiate(&f->step_graph, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            f->graph_N = f->N; f->graph_m = m; f->graph_dt = dt; f->graph_mu = f->mu; f->graph_seq = f->seq_z;
+            f->graph_N = f->N; f->graph_m = m; f->graph_dt = dt; f->graph_mu = f->mu; f->graph_P = f->P; f->graph_seq = f->seq_z;
             f->graph_frames = f->seq_frames;
             // the captured launches did not execute: the pointer swaps of launch_predict netted to zero
         }

@@ -119,7 +119,8 @@ struct ekfvio_filter {
     hipGraphExec_t step_graph = nullptr;
     int graph_N = -1, graph_m = -1, graph_frames = -1;
     float graph_dt = -1.f;
-    float* graph_mu = nullptr;      // orientation of the mean buffers at capture time
+    float* graph_mu = nullptr;      // orientation of the mean / covariance ping-pong at capture time
+    float* graph_P = nullptr;
     const void* graph_seq = nullptr;
     int use_graph = 1;
 

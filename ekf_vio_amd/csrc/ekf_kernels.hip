@@ -127,91 +127,114 @@ __device__ inline float two_delta() { return (float)(2 * 1e-3); }
 
 // ---------------------------------------------------------------------------------------
 // numericallyLinearizeProcess + mean propagation in one launch.
-// Block 0 additionally produces the 22x22 base block A and the propagated base mean.
-// Every block first evaluates the 19 base-state variants (unperturbed + 9 columns x {+,-})
-// that the landmark rows need, into LDS; then one lane per landmark evaluates its 24
-// perturbed motions plus the propagated mean and writes its 3x9 and 3x3 Jacobian blocks.
+// Workgroups 0 .. ceil(N/8)-1: 8 landmarks each, 32 lanes per landmark.  Every workgroup
+// first evaluates the 19 base-state variants (unperturbed + 9 columns x {+,-}) the landmark
+// rows need into LDS; then lane e < 25 of a landmark evaluates ONE motion (18 base
+// perturbations, 6 own perturbations, the propagated mean) and the finite differences are
+// formed through LDS.  The last workgroup produces the 22x22 base block A (32 evaluations of
+// convolveBaseState on 32 lanes) and the propagated base mean.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void linearize_kernel(const float* __restrict__ mu, int N, float dt, float* FA,
-                                                       float* FB, float* FD, float* mu_next) {
+#define LIN_LM 8
+__global__ __launch_bounds__(256) void linearize_kernel(const float* __restrict__ mu, int N, float dt, float* FA,
+                                                        float* FB, float* FD, float* mu_next) {
     __shared__ float s_base[EKF_BASE];
     __shared__ BaseMotion s_bm[19];            // 0: unperturbed, 1+2c: col 7+c plus, 2+2c: minus
-    __shared__ float s_hi[16][EKF_BASE];       // block 0: convolveBaseState at +delta
+    __shared__ float s_hi[16][EKF_BASE];       // base workgroup: convolveBaseState at +delta
     __shared__ float s_lo[16][EKF_BASE];
+    __shared__ float s_res[LIN_LM][25][3];
     const int tid = threadIdx.x;
     if (tid < EKF_BASE) s_base[tid] = mu[tid];
     __syncthreads();
+    const float td = two_delta();
+    if (blockIdx.x == gridDim.x - 1) {
+        if (tid < 32) {
+            // 32 evaluations of convolveBaseState: column j = 0..15, high and low test points
+            const int j = tid >> 1;
+            float t[EKF_BASE], o[EKF_BASE];
+#pragma unroll
+            for (int i = 0; i < EKF_BASE; i++) t[i] = (i == j) ? plus_delta(s_base[i]) : s_base[i];
+            if (tid & 1) {
+#pragma unroll
+                for (int i = 0; i < EKF_BASE; i++) t[i] = (i == j) ? minus_2delta(t[i]) : t[i];
+            }
+            convolve_base(t, dt, o);
+#pragma unroll
+            for (int i = 0; i < EKF_BASE; i++) (tid & 1 ? s_lo : s_hi)[j][i] = o[i];
+        } else if (tid == 32) {
+            float o[EKF_BASE];
+            convolve_base(s_base, dt, o);
+#pragma unroll
+            for (int i = 0; i < EKF_BASE; i++) mu_next[i] = o[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) {
+            const int j = e / EKF_BASE, i = e % EKF_BASE;
+            FA[e] = (j < 16) ? (s_hi[j][i] - s_lo[j][i]) / td : ((i == j) ? 1.f : 0.f);
+        }
+        return;
+    }
     if (tid < 19) {
         float t[EKF_BASE];
+#pragma unroll
         for (int i = 0; i < EKF_BASE; i++) t[i] = s_base[i];
         if (tid > 0) {
-            int c = 7 + (tid - 1) / 2;
-            t[c] = plus_delta(t[c]);
-            if (((tid - 1) & 1) == 1) t[c] = minus_2delta(t[c]);
+            const int c = 7 + (tid - 1) / 2;
+#pragma unroll
+            for (int i = 7; i < 16; i++) {
+                if (i == c) {
+                    t[i] = plus_delta(t[i]);
+                    if (((tid - 1) & 1) == 1) t[i] = minus_2delta(t[i]);
+                }
+            }
         }
         s_bm[tid] = base_motion(t, dt);
     }
-    if (blockIdx.x == 0 && tid >= 32 && tid < 64) {
-        // 32 evaluations of convolveBaseState: column j = 0..15, high and low test points
-        int e = tid - 32;
-        int j = e >> 1;
-        float t[EKF_BASE], o[EKF_BASE];
-        for (int i = 0; i < EKF_BASE; i++) t[i] = s_base[i];
-        t[j] = plus_delta(t[j]);
-        if (e & 1) t[j] = minus_2delta(t[j]);
-        convolve_base(t, dt, o);
-        for (int i = 0; i < EKF_BASE; i++) (e & 1 ? s_lo : s_hi)[j][i] = o[i];
+    __syncthreads();
+    const int lm = tid >> 5, e = tid & 31;
+    const int f = blockIdx.x * LIN_LM + lm;
+    const bool live = f < N;
+    float u = 0.f, v = 0.f, rho = 1.f;
+    if (live) {
+        u = mu[EKF_BASE + 3 * f];
+        v = mu[EKF_BASE + 3 * f + 1];
+        rho = mu[EKF_BASE + 3 * f + 2];
+    }
+    if (live && e < 25) {
+        V3 o;
+        if (e < 18) {
+            o = convolve_feature(s_bm[1 + e], u, v, rho);  // column 7 + e/2, plus (even) / minus (odd)  (:223-253)
+        } else if (e < 24) {
+            // the landmark's own 3x3 block (:262-321): component (e-18)/2, plus then minus
+            const int c = (e - 18) >> 1;
+            float t0 = u, t1 = v, t2 = rho;
+            if (c == 0) t0 = plus_delta(t0);
+            if (c == 1) t1 = plus_delta(t1);
+            if (c == 2) t2 = plus_delta(t2);
+            if (e & 1) {
+                if (c == 0) t0 = minus_2delta(t0);
+                if (c == 1) t1 = minus_2delta(t1);
+                if (c == 2) t2 = minus_2delta(t2);
+            }
+            o = convolve_feature(s_bm[0], t0, t1, t2);
+        } else {
+            o = convolve_feature(s_bm[0], u, v, rho);  // mean propagation with the OLD base state (:102-104)
+        }
+        s_res[lm][e][0] = o.x;
+        s_res[lm][e][1] = o.y;
+        s_res[lm][e][2] = o.z;
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        const float td = two_delta();
-        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 64) {
-            int j = e / EKF_BASE, i = e % EKF_BASE;
-            float v;
-            if (j < 16)
-                v = (s_hi[j][i] - s_lo[j][i]) / td;
-            else
-                v = (i == j) ? 1.f : 0.f;
-            FA[e] = v;
-        }
-        if (tid == 0) {
-            float o[EKF_BASE];
-            convolve_base(s_base, dt, o);
-            for (int i = 0; i < EKF_BASE; i++) mu_next[i] = o[i];
-        }
+    if (!live) return;
+    if (e < 12) {
+        // derivative column e: 0..8 -> state columns 7..15 (FB), 9..11 -> own block (FD)
+        float* o = (e < 9) ? (FB + (size_t)f * 27 + e * 3) : (FD + (size_t)f * 9 + (e - 9) * 3);
+#pragma unroll
+        for (int r = 0; r < 3; r++) o[r] = (s_res[lm][2 * e][r] - s_res[lm][2 * e + 1][r]) / td;
+    } else if (e == 24) {
+        mu_next[EKF_BASE + 3 * f] = s_res[lm][24][0];
+        mu_next[EKF_BASE + 3 * f + 1] = s_res[lm][24][1];
+        mu_next[EKF_BASE + 3 * f + 2] = s_res[lm][24][2];
     }
-    const int f = blockIdx.x * 64 + tid;
-    if (f >= N) return;
-    const float u = mu[EKF_BASE + 3 * f], v = mu[EKF_BASE + 3 * f + 1], rho = mu[EKF_BASE + 3 * f + 2];
-    const float td = two_delta();
-    // columns 7..15 of the landmark's rows (:223-253)
-    for (int c = 0; c < 9; c++) {
-        V3 hi = convolve_feature(s_bm[1 + 2 * c], u, v, rho);
-        V3 lo = convolve_feature(s_bm[2 + 2 * c], u, v, rho);
-        float* o = FB + (size_t)f * 27 + c * 3;
-        o[0] = (hi.x - lo.x) / td;
-        o[1] = (hi.y - lo.y) / td;
-        o[2] = (hi.z - lo.z) / td;
-    }
-    // the landmark's own 3x3 block (:262-321)
-    float base3[3] = {u, v, rho};
-    for (int c = 0; c < 3; c++) {
-        float t[3] = {u, v, rho};
-        t[c] = plus_delta(t[c]);
-        V3 hi = convolve_feature(s_bm[0], t[0], t[1], t[2]);
-        t[c] = minus_2delta(t[c]);
-        V3 lo = convolve_feature(s_bm[0], t[0], t[1], t[2]);
-        t[c] = base3[c];
-        float* o = FD + (size_t)f * 9 + c * 3;
-        o[0] = (hi.x - lo.x) / td;
-        o[1] = (hi.y - lo.y) / td;
-        o[2] = (hi.z - lo.z) / td;
-    }
-    // mean propagation with the OLD base state (:102-104)
-    V3 pm = convolve_feature(s_bm[0], u, v, rho);
-    mu_next[EKF_BASE + 3 * f] = pm.x;
-    mu_next[EKF_BASE + 3 * f + 1] = pm.y;
-    mu_next[EKF_BASE + 3 * f + 2] = pm.z;
 }
 
 // Scatter the Jacobian blocks into a dense n x n matrix (column-major, ld), zero elsewhere.
@@ -243,27 +266,6 @@ __global__ void build_dense_F_kernel(const float* FA, const float* FB, const flo
 // order of the reference's sparse products (and of the dense oracle, whose extra terms are
 // exact zeros).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void predict_x_kernel(const float* __restrict__ P, int ld, int n,
-                                                        const float* __restrict__ FA, const float* __restrict__ FB,
-                                                        const float* __restrict__ FD, float* __restrict__ X) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i >= n) return;
-    const float* pc = P + (size_t)j * ld;
-    float acc = 0.f;
-    if (i < EKF_BASE) {
-        for (int k = 0; k < EKF_BASE; k++) acc = acc + FA[k * EKF_BASE + i] * pc[k];
-    } else {
-        const int f = (i - EKF_BASE) / 3, r = (i - EKF_BASE) % 3;
-        const float* b = FB + (size_t)f * 27 + r;
-        for (int c = 0; c < 9; c++) acc = acc + b[c * 3] * pc[7 + c];
-        const float* d = FD + (size_t)f * 9 + r;
-        const int k0 = EKF_BASE + 3 * f;
-        for (int q = 0; q < 3; q++) acc = acc + d[q * 3] * pc[k0 + q];
-    }
-    X[(size_t)j * ld + i] = acc;
-}
-
 __device__ inline float process_noise(int i, float dt) {
     // generateProcessNoise (:123-174)
     if (i < 7) return (float)(0.0001 * (double)dt);
@@ -273,26 +275,175 @@ __device__ inline float process_noise(int i, float dt) {
     return (float)(0.0001 * (double)dt);
 }
 
-__global__ __launch_bounds__(256) void predict_p_kernel(const float* __restrict__ X, int ld, int n,
-                                                        const float* __restrict__ FA, const float* __restrict__ FB,
-                                                        const float* __restrict__ FD, float dt, float* __restrict__ Pout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i >= n) return;
-    float acc = 0.f;
-    if (j < EKF_BASE) {
-        for (int k = 0; k < EKF_BASE; k++) acc = acc + X[(size_t)k * ld + i] * FA[k * EKF_BASE + j];
-    } else {
-        const int g = (j - EKF_BASE) / 3, s = (j - EKF_BASE) % 3;
-        const float* b = FB + (size_t)g * 27 + s;
-        for (int c = 0; c < 9; c++) acc = acc + X[(size_t)(7 + c) * ld + i] * b[c * 3];
-        const float* d = FD + (size_t)g * 9 + s;
-        const int k0 = EKF_BASE + 3 * g;
-        for (int q = 0; q < 3; q++) acc = acc + X[(size_t)(k0 + q) * ld + i] * d[q * 3];
-    }
+// ---------------------------------------------------------------------------------------
+// Fused structured propagation  P' = F P F^T + Q  in ONE pass (out of place).
+// Because F = [[A 0],[B D]], the 3x3 block of P' for the landmark pair (f,g) depends only on
+// the 12x12 sub-block P[{7..15} U own(f), {7..15} U own(g)], so a workgroup owning 16x16
+// landmark pairs stages the shared parts (9x9 base block, 9x3 / 3x9 strips, Jacobian blocks)
+// in LDS and every thread finishes one 3x3 block with the intermediate X = F P kept in
+// registers.  Base rows / columns are handled by extra workgroups of the same launch, one
+// thread per element.  Every sum runs in ascending state index with separate multiply and
+// add (X = F*P first, then X*F^T), i.e. the order of the reference's sparse products.
+// ---------------------------------------------------------------------------------------
+#define PT 16  // landmarks per tile side (landmark x landmark tiles)
+#define PC 21  // landmarks per chunk (63 state rows / columns) in the base-row / base-column workgroups
+
+__device__ __forceinline__ float predict_finish(float acc, int i, int j, float dt) {
     if (i == j) acc = acc + process_noise(i, dt);
-    if (!(fabsf(acc) > EKF_FLUSH_THRESH)) acc = 0.f;
-    Pout[(size_t)j * ld + i] = acc;
+    return (fabsf(acc) > EKF_FLUSH_THRESH) ? acc : 0.f;
+}
+
+// grid.x = tiles_side^2 landmark tiles + (1 + chunks) base-row workgroups + chunks base-column workgroups
+__global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restrict__ P, int ld, int N, int n,
+                                                            const float* __restrict__ FA, const float* __restrict__ FB,
+                                                            const float* __restrict__ FD, float dt,
+                                                            float* __restrict__ Pout, int tiles_side, int chunks) {
+    const int tid = threadIdx.x;
+    const int ntile = tiles_side * tiles_side;
+    __shared__ float sm[4096];
+    if ((int)blockIdx.x < ntile) {
+        float* sPbb = sm;                 // [81]      P(7+a, 7+b) at a*9+b
+        float* sPbg = sm + 96;            // [PT][27]  P(7+a, 22+3g+s) at a*3+s
+        float* sPfb = sPbg + PT * 27;     // [PT][27]  P(22+3f+q, 7+b) at q*9+b
+        float* sBf = sPfb + PT * 27;      // [PT][27]  B_f(r,c) at c*3+r
+        float* sBg = sBf + PT * 27;
+        float* sDf = sBg + PT * 27;       // [PT][9]   D_f(r,q) at q*3+r
+        float* sDg = sDf + PT * 9;
+        float* sXb = sDg + PT * 9;        // [PT][27]  X(22+3f+r, 7+b) at r*9+b
+        const int tI = blockIdx.x / tiles_side, tJ = blockIdx.x % tiles_side;
+        const int f0 = tI * PT, g0 = tJ * PT;
+        if (tid < 81) sPbb[tid] = P[(size_t)(7 + tid % 9) * ld + 7 + tid / 9];
+        for (int e = tid; e < PT * 27; e += 256) {
+            const int l = e / 27, w = e % 27;
+            const int f = f0 + l, g = g0 + l;
+            sPbg[e] = (g < N) ? P[(size_t)(EKF_BASE + 3 * g + w % 3) * ld + 7 + w / 3] : 0.f;
+            sPfb[e] = (f < N) ? P[(size_t)(7 + w % 9) * ld + EKF_BASE + 3 * f + w / 9] : 0.f;
+            sBf[e] = (f < N) ? FB[(size_t)f * 27 + w] : 0.f;
+            sBg[e] = (g < N) ? FB[(size_t)g * 27 + w] : 0.f;
+        }
+        for (int e = tid; e < PT * 9; e += 256) {
+            const int l = e / 9, w = e % 9;
+            sDf[e] = (f0 + l < N) ? FD[(size_t)(f0 + l) * 9 + w] : 0.f;
+            sDg[e] = (g0 + l < N) ? FD[(size_t)(g0 + l) * 9 + w] : 0.f;
+        }
+        __syncthreads();
+        // X on the base columns, once per landmark row of the tile
+        for (int e = tid; e < PT * 27; e += 256) {
+            const int l = e / 27, r = (e % 27) / 9, b = e % 9;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 9; c++) acc = acc + sBf[l * 27 + c * 3 + r] * sPbb[c * 9 + b];
+#pragma unroll
+            for (int q = 0; q < 3; q++) acc = acc + sDf[l * 9 + q * 3 + r] * sPfb[l * 27 + q * 9 + b];
+            sXb[e] = acc;
+        }
+        __syncthreads();
+        const int lf = tid / PT, lg = tid % PT;
+        const int f = f0 + lf, g = g0 + lg;
+        if (f >= N || g >= N) return;
+        float Pfg[3][3];  // own block P(22+3f+q, 22+3g+s)
+#pragma unroll
+        for (int sIdx = 0; sIdx < 3; sIdx++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) Pfg[q][sIdx] = P[(size_t)(EKF_BASE + 3 * g + sIdx) * ld + EKF_BASE + 3 * f + q];
+        float Xg[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int sIdx = 0; sIdx < 3; sIdx++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 9; c++) acc = acc + sBf[lf * 27 + c * 3 + r] * sPbg[lg * 27 + c * 3 + sIdx];
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc = acc + sDf[lf * 9 + q * 3 + r] * Pfg[q][sIdx];
+                Xg[r][sIdx] = acc;
+            }
+#pragma unroll
+        for (int sIdx = 0; sIdx < 3; sIdx++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 9; c++) acc = acc + sXb[lf * 27 + r * 9 + c] * sBg[lg * 27 + c * 3 + sIdx];
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc = acc + Xg[r][q] * sDg[lg * 9 + q * 3 + sIdx];
+                const int i = EKF_BASE + 3 * f + r, j = EKF_BASE + 3 * g + sIdx;
+                Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
+            }
+        return;
+    }
+    const int wb = (int)blockIdx.x - ntile;
+    float* sA = sm;                        // [22*22]  A(i,l) at l*22+i
+    for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) sA[e] = FA[e];
+    if (wb <= chunks) {
+        // ---- base rows: i < 22; columns j < 22 (wb == 0) or the 63 columns of landmark chunk wb-1 ----
+        float* sX1 = sm + 512;             // [22][22]  X(i,k), k < 22, at k*22+i
+        float* sX2 = sm + 1024;            // [63][22]  X(i, j0+jc) at jc*22+i
+        __syncthreads();
+        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) {
+            const int i = e % EKF_BASE, k = e / EKF_BASE;
+            const float* pc = P + (size_t)k * ld;
+            float acc = 0.f;
+            for (int l = 0; l < EKF_BASE; l++) acc = acc + sA[l * EKF_BASE + i] * pc[l];
+            sX1[e] = acc;
+        }
+        if (wb == 0) {
+            __syncthreads();
+            for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) {
+                const int i = e % EKF_BASE, j = e / EKF_BASE;
+                float acc = 0.f;
+                for (int k = 0; k < EKF_BASE; k++) acc = acc + sX1[k * EKF_BASE + i] * sA[k * EKF_BASE + j];
+                Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
+            }
+            return;
+        }
+        const int g0 = (wb - 1) * PC, j0 = EKF_BASE + 3 * g0;
+        const int ncol = min(3 * PC, n - j0);
+        for (int e = tid; e < EKF_BASE * ncol; e += 256) {
+            const int i = e % EKF_BASE, jc = e / EKF_BASE;
+            const float* pc = P + (size_t)(j0 + jc) * ld;
+            float acc = 0.f;
+            for (int l = 0; l < EKF_BASE; l++) acc = acc + sA[l * EKF_BASE + i] * pc[l];
+            sX2[e] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < EKF_BASE * ncol; e += 256) {
+            const int i = e % EKF_BASE, jc = e / EKF_BASE;
+            const int g = g0 + jc / 3, sIdx = jc % 3, j = j0 + jc;
+            const float* b = FB + (size_t)g * 27 + sIdx;
+            const float* d = FD + (size_t)g * 9 + sIdx;
+            float acc = 0.f;
+            for (int c = 0; c < 9; c++) acc = acc + sX1[(7 + c) * EKF_BASE + i] * b[c * 3];
+            for (int q = 0; q < 3; q++) acc = acc + sX2[(3 * (jc / 3) + q) * EKF_BASE + i] * d[q * 3];
+            Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
+        }
+        return;
+    }
+    // ---- base columns: j < 22; rows of landmark chunk wb-chunks-1 ----
+    {
+        float* sX3 = sm + 512;             // [22][64]  X(i0+ic, k), k < 22, at k*64+ic
+        const int f0 = (wb - chunks - 1) * PC, i0 = EKF_BASE + 3 * f0;
+        const int nrow = min(3 * PC, n - i0);
+        for (int e = tid; e < nrow * EKF_BASE; e += 256) {
+            const int ic = e % nrow, k = e / nrow;
+            const int f = f0 + ic / 3, r = ic % 3;
+            const float* pc = P + (size_t)k * ld;
+            const float* b = FB + (size_t)f * 27 + r;
+            const float* d = FD + (size_t)f * 9 + r;
+            float acc = 0.f;
+            for (int c = 0; c < 9; c++) acc = acc + b[c * 3] * pc[7 + c];
+            for (int q = 0; q < 3; q++) acc = acc + d[q * 3] * pc[EKF_BASE + 3 * f + q];
+            sX3[k * 64 + ic] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < nrow * EKF_BASE; e += 256) {
+            const int ic = e % nrow, j = e / nrow;
+            float acc = 0.f;
+            for (int k = 0; k < EKF_BASE; k++) acc = acc + sX3[k * 64 + ic] * sA[k * EKF_BASE + j];
+            const int i = i0 + ic;
+            Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
+        }
+    }
 }
 
 // dense mode epilogue: P += Q(dt) on the diagonal, then prune
@@ -491,9 +642,8 @@ __global__ void check_sigma_kernel(const float* P, int ld, int n, float* out) {
 // ---------------------------------------------------------------------------------------
 void launch_linearize(ekfvio_filter* f, float dt) {
     ProfScope ps(f, PC_LINEARIZE);
-    int blocks = (f->N + 63) / 64;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(linearize_kernel, dim3(blocks), dim3(64), 0, f->stream, f->mu, f->N, dt, f->FA, f->FB, f->FD,
+    const int blocks = (f->N + LIN_LM - 1) / LIN_LM + 1;  // landmark workgroups + the base-block workgroup
+    hipLaunchKernelGGL(linearize_kernel, dim3(blocks), dim3(256), 0, f->stream, f->mu, f->N, dt, f->FA, f->FB, f->FD,
                        f->mu_next);
 }
 
@@ -521,9 +671,11 @@ void launch_predict(ekfvio_filter* f, float dt) {
         hipLaunchKernelGGL(add_noise_flush_kernel, grid, dim3(256), 0, f->stream, f->P, ld, n, dt);
     } else {
         ProfScope ps(f, PC_PREDICT, 4.0 * n * (358.0 + 36.0 * f->N));
-        hipLaunchKernelGGL(predict_x_kernel, grid, dim3(256), 0, f->stream, f->P, ld, n, f->FA, f->FB, f->FD, f->P2);
-        hipLaunchKernelGGL(predict_p_kernel, grid, dim3(256), 0, f->stream, f->P2, ld, n, f->FA, f->FB, f->FD, dt,
-                           f->P);
+        const int ts = (f->N + PT - 1) / PT;
+        const int chunks = (f->N + PC - 1) / PC;
+        hipLaunchKernelGGL(predict_fused_kernel, dim3(ts * ts + 1 + 2 * chunks), dim3(256), 0, f->stream, f->P, ld, f->N, n,
+                           f->FA, f->FB, f->FD, dt, f->P2, ts, chunks);
+        std::swap(f->P, f->P2);  // out of place; P2's padding is zero as well (never written outside n x n)
     }
     // the propagated mean becomes the state (landmarks used the OLD base state, :102-107)
     std::swap(f->mu, f->mu_next);
