@@ -438,6 +438,20 @@ int ekfvio_profile_enable(ekfvio_filter* f, int32_t on) {
     if (!f) return EKFVIO_EINVAL;
     hipStreamSynchronize(f->stream);
     f->prof_on = on != 0;
+    if (f->prof_on) {
+        // calibrate the cost of an (ev0, ev1) pair with nothing in between
+        double acc = 0;
+        const int reps = 32;
+        for (int i = 0; i < reps + 4; i++) {
+            (void)hipEventRecord(f->ev0, f->stream);
+            (void)hipEventRecord(f->ev1, f->stream);
+            (void)hipEventSynchronize(f->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, f->ev0, f->ev1);
+            if (i >= 4) acc += ms;
+        }
+        f->prof_overhead_ms = (float)(acc / reps);
+    }
     return EKFVIO_OK;
 }
 int ekfvio_profile_reset(ekfvio_filter* f) {

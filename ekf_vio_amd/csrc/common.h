@@ -126,6 +126,7 @@ struct ekfvio_filter {
 
     // --- profiler ---
     bool prof_on = false;
+    float prof_overhead_ms = 0.f;  // elapsed time of an empty event pair, subtracted from every scope
     ProfSlot prof[PC_COUNT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -184,7 +185,8 @@ void klt_free(ekfvio_filter* f);
 struct ProfScope {
     ekfvio_filter* f;
     int cls;
-    ProfScope(ekfvio_filter* f_, int cls_, double flops = 0) : f(f_), cls(cls_) {
+    int launches;
+    ProfScope(ekfvio_filter* f_, int cls_, double flops = 0, int launches_ = 1) : f(f_), cls(cls_), launches(launches_) {
         if (f->prof_on) {
             (void)hipEventRecord(f->ev0, f->stream);
             f->prof[cls].flops += flops;
@@ -196,8 +198,8 @@ struct ProfScope {
             (void)hipEventSynchronize(f->ev1);
             float ms = 0;
             (void)hipEventElapsedTime(&ms, f->ev0, f->ev1);
-            f->prof[cls].ms += ms;
-            f->prof[cls].launches += 1;
+            f->prof[cls].ms += ms;  // raw: includes the event-pair overhead (f->prof_overhead_ms, reported separately)
+            f->prof[cls].launches += launches;
         }
     }
 };

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
                                                                   const float* __restrict__ mu, float* last_klt,
                                                                   uint8_t* del_flag, int* idx, int* inv_idx, float* yres,
                                                                   float* Rm, const int* frame_counter) {
-    __shared__ int s_cnt[1024];
+    __shared__ int s_cnt[32];
     __shared__ int s_total;
     const int tid = threadIdx.x;
     if (frame_counter) {
@@ -484,17 +484,30 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
     const int hi = min(N, lo + per);
     int c = 0;
     for (int i = lo; i < hi; i++) c += pass[i] ? 1 : 0;
-    s_cnt[tid] = c;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partial counts
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (tid >= off) ? s_cnt[tid - off] : 0;
-        __syncthreads();
-        s_cnt[tid] += v;
-        __syncthreads();
+    // exclusive scan of the 1024 per-thread counts: shuffle scan inside each wavefront, then
+    // the 16 wavefront totals are scanned by wavefront 0 (two barriers in all)
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    int base = s_cnt[tid] - c;
-    if (tid == 1023) s_total = s_cnt[1023];
+    if (lane == 63) s_cnt[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        int t = (lane < 16) ? s_cnt[lane] : 0;
+        int ti = t;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int v = __shfl_up(ti, off, 64);
+            if (lane >= off) ti += v;
+        }
+        if (lane < 16) s_cnt[16 + lane] = ti - t;  // exclusive prefix of the wavefront totals
+        if (lane == 15) s_total = ti;
+    }
+    __syncthreads();
+    int base = s_cnt[16 + wv] + incl - c;
     for (int i = lo; i < hi; i++) {
         if (pass[i]) {
             const int r = 2 * base;
@@ -538,6 +551,9 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
 // A(r,c) = S(c,r) so that the Cholesky kernels (which read the lower triangle) factor the
 // same numbers as the reference.  C = Sigma H^T (columns of Sigma); Wt = (H Sigma)^T (rows
 // of Sigma, transposed so that it is state-major).
+// One thread per element (a 64x64-tile variant that transposes through LDS to coalesce the
+// Sigma reads measured slower: 13 us vs 8 us at N = 256; the scattered reads are L2 hits and
+// 2048 small workgroups hide them better).
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P, int ld, int n,
                                                      const int* __restrict__ idx, const float* __restrict__ Rm, int m,
                                                      int m_pad, int n_pad, float* Saug, int lda, float* Wt,
@@ -710,8 +726,10 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda);
         launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
         {
-            // T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place; also G and K*y (column n)
-            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);
+            // The two P-update GEMMs, back to back (one profiler scope, two launches):
+            //   T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place; also G and K*y (column n)
+            //   Sigma' = T + G*K^T, pruned (:594-596, :625); workgroup (0,0) finishes the mean
+            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)(n + 1) * m_pad + 2.0 * n * (double)n * m_pad, 2);
             GemmEpi e1;
             e1.mode = 1;
             e1.inv_idx = f->inv_idx;
@@ -719,10 +737,6 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             e1.G = f->Gm;
             e1.ldg = ld;
             launch_gemm(f->stream, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
-        }
-        {
-            // Sigma' = T + G*K^T, pruned (:594-596, :625); workgroup (0,0) finishes the mean
-            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad);
             launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
         }
     } else {
