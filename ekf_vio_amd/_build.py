@@ -11,9 +11,13 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libekfvio_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
          "-ffp-contract=off",  # the reference's x86-64 build never fuses multiply-add (parity)
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+# per-file extras.  chol.hip: keep MFMA results in VGPRs: its dependent MFMA -> MFMA chains feed each
+# result straight back as an operand, and an AGPR destination costs a v_accvgpr_read per hop.
+FILE_FLAGS = {"chol.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -31,8 +35,25 @@ def _stale():
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB_PATH] + sources()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    jobs, objs = [], []
+    for src in sources():
+        name = os.path.basename(src)
+        obj = os.path.join(OBJ_DIR, name + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+                and os.path.getmtime(obj) >= newest_hdr):
+            continue
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

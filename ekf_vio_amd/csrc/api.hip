@@ -130,6 +130,14 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     HIPC(f, dev_alloc(f->stream, &f->Saug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->sweep_sync, 2 * (size_t)(f->m_cap / 64 > 128 ? f->m_cap / 64 : 128) + 4));
+    {
+        hipDeviceProp_t prop;
+        HIPC(f, hipGetDeviceProperties(&prop, device));
+        f->num_cus = prop.multiProcessorCount;
+        const char* e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
+        if (e) f->sweep_mode = atoi(e) ? 1 : 0;
+    }
     HIPC(f, dev_alloc(f->stream, &f->Km, pm));
     HIPC(f, dev_alloc(f->stream, &f->Wt, pm));
     HIPC(f, dev_alloc(f->stream, &f->Gm, pm));
@@ -147,7 +155,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     hipSetDevice(f->device);
     hipStreamSynchronize(f->stream);
     void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
-                    f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km,
+                    f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km, f->sweep_sync, f->sweep_dbg,
                     f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -367,6 +375,10 @@ int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z,
     return EKFVIO_OK;
 }
 
+// steps per captured graph: even (the mean / covariance ping-pong is back in its starting orientation)
+// and large enough to amortise the ~8 us a hipGraphLaunch costs between replays
+#define EKF_GRAPH_STEPS 8
+
 static void drop_graph(ekfvio_filter* f) {
     if (f->step_graph) {
         (void)hipGraphExecDestroy(f->step_graph);
@@ -381,7 +393,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
     int s = 0;
     // hipGraph path: the same measurement-row count for every frame (one launch geometry),
     // profiling off.  The bookkeeping kernel reads the frame index from a device counter.
-    bool uniform = f->use_graph && !f->prof_on && count >= 2;
+    bool uniform = f->use_graph && !f->prof_on && count >= EKF_GRAPH_STEPS;
     for (int i = 0; uniform && i < f->seq_frames; i++) uniform = f->seq_m[i] == f->seq_m[0];
     if (uniform) {
         const int m = f->seq_m[0];
@@ -394,7 +406,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
             hipGraph_t g = nullptr;
             HIPC(f, hipStreamSynchronize(f->stream));
             HIPC(f, hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < EKF_GRAPH_STEPS; k++) {
                 launch_predict(f, dt);
                 launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames);
             }
@@ -409,8 +421,8 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
             f->graph_frames = f->seq_frames;
             // the captured launches did not execute: the pointer swaps of launch_predict netted to zero
         }
-        for (; s + 2 <= count; s += 2) HIPC(f, hipGraphLaunch(f->step_graph, f->stream));
-        for (; s < count; s++) {  // odd remainder, eager, same counter-driven bookkeeping
+        for (; s + EKF_GRAPH_STEPS <= count; s += EKF_GRAPH_STEPS) HIPC(f, hipGraphLaunch(f->step_graph, f->stream));
+        for (; s < count; s++) {  // remainder, eager, same counter-driven bookkeeping
             launch_predict(f, dt);
             launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames);
         }
@@ -555,8 +567,9 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
 
 // Diagnostic: cycle stamps (s_memtime) of the phases of one 64x64 diagonal-block factorisation
 // on an SPD test block; stamps[0..11]: start, loaded, then after each panel factor / trailing
-// update (x4), inverse done, stored.
-int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[12]) {
+// update (x4), inverse done, stored; stamps[16 + 16*wave + i]: per-wavefront end of work of
+// phase i (2p: factor phase of panel p, 2p+1: column-update phase, 8: final phase).
+int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[80]) {
     if (!f || !stamps) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
     std::vector<float> hs(64 * 64);
@@ -567,12 +580,29 @@ int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[12]) {
     HIPC(f, dev_alloc(f->stream, &dS, hs.size()));
     HIPC(f, dev_alloc(f->stream, &dL, hs.size()));
     HIPC(f, dev_alloc(f->stream, &dLi, 4096));
-    HIPC(f, dev_alloc(f->stream, &dst, 12));
+    HIPC(f, dev_alloc(f->stream, &dst, 80));
+    HIPC(f, hipMemsetAsync(dst, 0, sizeof(long long) * 80, f->stream));
     HIPC(f, hipMemcpyAsync(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, f->stream));
     for (int rep = 0; rep < 3; rep++) launch_potrf_stamps(f, dS, 64, dL, dLi, dst);
-    HIPC(f, hipMemcpyAsync(stamps, dst, sizeof(long long) * 12, hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipMemcpyAsync(stamps, dst, sizeof(long long) * 80, hipMemcpyDeviceToHost, f->stream));
     HIPC(f, hipStreamSynchronize(f->stream));
     hipFree(dS); hipFree(dL); hipFree(dLi); hipFree(dst);
+    return EKFVIO_OK;
+}
+
+// Diagnostic: stamps[512] of the persistent sweep's last run (chain: [0],[1], then 8 per block step
+// from [8]; first helper: 8 per block step from [256]).  enable != 0 allocates and arms the buffer.
+int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t* stamps /* [1024] */) {
+    if (!f) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    if (enable && !f->sweep_dbg) {
+        HIPC(f, dev_alloc(f->stream, &f->sweep_dbg, 1024));
+        HIPC(f, hipMemsetAsync(f->sweep_dbg, 0, 1024 * sizeof(long long), f->stream));
+    }
+    if (stamps && f->sweep_dbg) {
+        HIPC(f, hipMemcpyAsync(stamps, f->sweep_dbg, 1024 * sizeof(long long), hipMemcpyDeviceToHost, f->stream));
+        HIPC(f, hipStreamSynchronize(f->stream));
+    }
     return EKFVIO_OK;
 }
 

@@ -27,6 +27,8 @@
 // with a row stride of 65 floats: conflict-free for both operand orientations.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -44,6 +46,29 @@ __device__ __forceinline__ double lane_bcast_d(double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+// acc -= a(lane R of this lane's 16-lane row) * b   — one VALU op, no SGPR round trip.
+// The DPP operand must not have been written by the VALU in the two preceding issue slots
+// (CDNA3 ISA 4.5, "VALU writes VGPR -> DPP reads that VGPR"): callers keep it old.
+template <int R>
+__device__ __forceinline__ void dpp_fnma(float& acc, float a, float b) {
+    asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(R));
+}
+// a(lane R of this lane's 16-lane row) * b
+template <int R>
+__device__ __forceinline__ float dpp_mul(float a, float b) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a), "v"(b), "n"(R));
+    return r;
 }
 
 // ---- tile movers (256 threads) ---------------------------------------------------------
@@ -65,6 +90,17 @@ __device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G
         const int c = e >> 4, r4 = (e & 15) * 4;
         const float* t = T + c * PLD + r4;
         *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+// lower triangle of a diagonal tile; the strict upper triangle is written as zero
+__device__ __forceinline__ void store_tile_lower(const float* T, float* __restrict__ G, int ld, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int e = tid + it * 256;
+        const int c = e >> 4, r4 = (e & 15) * 4;
+        const float* t = T + c * PLD + r4;
+        *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) =
+            make_float4(r4 >= c ? t[0] : 0.f, r4 + 1 >= c ? t[1] : 0.f, r4 + 2 >= c ? t[2] : 0.f, r4 + 3 >= c ? t[3] : 0.f);
     }
 }
 // four 16x16 inverse blocks (global: block p at p*256, column-major ld 16) <-> LDS (stride ILD)
@@ -114,32 +150,97 @@ __device__ __forceinline__ f32x4 mma16(const float* As, int a_si, int a_sq, cons
 
 // X <- X L^-T for a 64x64 tile X (Tx) against the lower-triangular 64x64 block in Tl, given
 // the inverses of its four 16x16 diagonal blocks (Tinv).  Wavefront w owns rows 16w..16w+15;
-// no barrier inside.
-__device__ __forceinline__ void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
-    const int r0 = 16 * wave, li = lane & 15, lk = lane >> 4;
+// no barrier inside.  The 16x64 row block lives in MFMA accumulator layout for the whole
+// substitution (lane l, block b, register v <-> X(16w + l%16, 16b + 4*(l/16) + v)): a result
+// register v is fed straight back as the k-slice {4g+v} of the next product's A operand (the
+// B operand is read from LDS with the matching k permutation), so the dependent chain is
+// MFMA -> MFMA with no LDS round trip; all B operands are preloaded.
+template <int NT>
+__device__ __forceinline__ void tri_solve_fwd_n(float* const (&Txs)[NT], const float* Tl, const float* Tinv, int wave, int lane) {
+    const int r0 = 16 * wave, li = lane & 15, g = lane >> 4;
+    f32x4 x[NT][4];
+    float binv[4][4];   // Inv_p(li, 4g+v)
+    float nl[6][4];     // -L(16t+li, 16p+4g+v), (p,t) pairs in the order (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) x[n][b][v] = Txs[n][(16 * b + 4 * g + v) * PLD + r0 + li];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) binv[p][v] = Tinv[p * 16 * ILD + (4 * g + v) * ILD + li];
+    {
+        int e = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int t = p + 1; t < 4; t++, e++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) nl[e][v] = -Tl[(16 * p + 4 * g + v) * PLD + 16 * t + li];
+    }
+    // pin every operand in a register here: otherwise the LDS reads are sunk next to their MFMA
+    // and their latency lands on the dependent chain
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) asm volatile("" : "+v"(binv[p][v]));
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) asm volatile("" : "+v"(nl[q][v]));
+    int e0 = 0;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        // Y_p(i,j) = sum_q X(r0+i, 16p+q) Inv_p(j,q)
-        const f32x4 y = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tinv + p * 16 * ILD, 1, ILD, lane);
+        f32x4 y[NT];
 #pragma unroll
-        for (int g = 0; g < 4; g++) Tx[(16 * p + 4 * lk + g) * PLD + r0 + li] = y[g];
+        for (int n = 0; n < NT; n++) y[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the NT tiles are independent chains: interleaved they keep the MFMA pipe busy
 #pragma unroll
-        for (int t = p + 1; t < 4; t++) {
-            // X(r0+i, 16t+j) -= sum_q Y_p(i,q) L(16t+j, 16p+q)
-            const f32x4 u = mma16(Tx + 16 * p * PLD + r0, 1, PLD, Tl + 16 * p * PLD + 16 * t, 1, PLD, lane);
+        for (int v = 0; v < 4; v++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) Tx[(16 * t + 4 * lk + g) * PLD + r0 + li] -= u[g];
-        }
+            for (int n = 0; n < NT; n++) y[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(binv[p][v], x[n][p][v], y[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; n++) x[n][p] = y[n];
+        int e = e0;
+#pragma unroll
+        for (int t = p + 1; t < 4; t++, e++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) x[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(nl[e][v], y[n][v], x[n][t], 0, 0, 0);
+        e0 = e;
     }
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Txs[n][(16 * b + 4 * g + v) * PLD + r0 + li] = x[n][b][v];
+}
+__device__ __forceinline__ void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
+    float* const t[1] = {Tx};
+    tri_solve_fwd_n<1>(t, Tl, Tinv, wave, lane);
+}
+__device__ __forceinline__ void tri_solve_fwd2(float* Tx, float* Ty, const float* Tl, const float* Tinv, int wave, int lane) {
+    float* const t[2] = {Tx, Ty};
+    tri_solve_fwd_n<2>(t, Tl, Tinv, wave, lane);
 }
 #define POTRF_STAMP(i)                                                         \
     do {                                                                       \
         if (stamps && tid == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
 
+#define POTRF_WSTAMP(i)                                                                               \
+    do {                                                                                              \
+        if (stamps && lane == 0) stamps[16 + wave * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 // ---- 64x64 Cholesky inside one workgroup ------------------------------------------------
 // A: LDS tile holding (at least) the lower triangle of an SPD block; on return its lower
-// triangle is L and the strict upper triangle is zero.  Tinv receives the inverses of the
+// triangle is L (the strict upper triangle is left as it was: store with store_tile_lower).
+// Tinv receives the inverses of the
 // four 16x16 diagonal blocks of L.  Returns true if a pivot was <= 0.
 //
 // Four 16-column micro-panels.  Only the pivot chain is serial: wavefront 0 holds one matrix
@@ -167,17 +268,23 @@ __device__ __forceinline__ void potrf_inverse16(const float* A, float* Tinv, int
     const int o = 16 * b, li = lane & 15;
     float lrow[16], acc[16], x[16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) lrow[q] = A[(o + q) * PLD + o + li];  // L(o+li, o+q)
-    const float dinv_own = 1.0f / A[(o + li) * PLD + o + li];
+    for (int q = 0; q < 16; q++) lrow[q] = A[(o + q) * PLD + o + li];  // L(o+li, o+q), same in all four lane rows
+    const float dd = A[(o + li) * PLD + o + li];
+    float dinv_own = __builtin_amdgcn_rcpf(dd);
+    dinv_own = __builtin_fmaf(__builtin_fmaf(-dd, dinv_own, 1.f), dinv_own, dinv_own);  // one Newton step: ~0.5 ulp
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = (r == li) ? 1.f : 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const float xq = acc[q] * lane_bcast(dinv_own, q);
+    // x(q) = acc(q) / L(q,q);  acc(r) -= L(r,q) x(q): L(r,q) sits in lane r of every 16-lane row and
+    // reaches the other lanes as the DPP operand of the multiply-add itself (row_newbcast)
+    static_for<0, 16>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const float xq = dpp_mul<q>(dinv_own, acc[q]);
         x[q] = xq;
-#pragma unroll
-        for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fmaf(-lane_bcast(lrow[q], r), xq, acc[r]);
-    }
+        static_for<q + 1, 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            dpp_fnma<r>(acc[r], lrow[q], xq);
+        });
+    });
     if (lane < 16) {
 #pragma unroll
         for (int r = 0; r < 16; r++) Tinv[b * 16 * ILD + li * ILD + r] = x[r];
@@ -198,15 +305,14 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
 #pragma unroll
             for (int j = 0; j < 16; j++) a[j] = A[(c0 + j) * PLD + lane];
 #pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("" : "+v"(a[j]));  // all LDS reads issue before the chain
+#pragma unroll
             for (int k = 0; k < 16; k++) {
-                float d = lane_bcast(a[k], c0 + k);
-                if (!(d > 0.f)) {
-                    bad = true;
-                    d = 1e-20f;
-                }
+                // a non-positive (or NaN) pivot is clamped so the state stays finite; it leaves
+                // L_kk = 1e-10 behind, which the caller's final diagonal check reports
+                const float d = lane_bcast(fmaxf(a[k], 1e-20f), c0 + k);
                 const float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, <= 1 ulp
-                const float lkk = d * inv;
-                a[k] = (lane == c0 + k) ? lkk : a[k] * inv;
+                a[k] *= inv;                                 // lane c0+k: d * inv = L_kk
 #pragma unroll
                 for (int j = k + 1; j < 16; j++) {
                     const float sj = lane_bcast(a[k], c0 + j);
@@ -231,27 +337,23 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
         } else if (p == 3) {
             if (wave == 3) potrf_inverse16(A, Tinv, 2, lane);
         }
+        POTRF_WSTAMP(2 * p);
         __syncthreads();
         POTRF_STAMP(2 + 2 * p);
         // ---- phase C: panel p's update of the next panel's columns (tiles (ti,0)) ----
         if (p < 3) {
             if (wave < 3 - p) potrf_tile_update(A, c0, wave, 0, lane);
+            POTRF_WSTAMP(2 * p + 1);
             __syncthreads();
         }
         POTRF_STAMP(3 + 2 * p);
     }
-    // zero the strict upper triangle (the tile may have carried the symmetric upper part);
-    // wave 0 inverts the last diagonal block meanwhile (it only reads on/below the diagonal)
-    if (wave == 0) {
-        potrf_inverse16(A, Tinv, 3, lane);
-    } else {
-        for (int e = tid - 64; e < PB * PB; e += 192) {
-            const int r = e % PB, c = e / PB;
-            if (r < c) A[c * PLD + r] = 0.f;
-        }
-    }
+    // the strict upper triangle still holds the symmetric input: store_tile_lower drops it
+    if (wave == 0) potrf_inverse16(A, Tinv, 3, lane);
+    POTRF_WSTAMP(8);
     __syncthreads();
     POTRF_STAMP(10);
+    if (wave == 0) bad = __ballot(!(A[lane * PLD + lane] > 2e-10f)) != 0ull;
     return bad;
 }
 
@@ -265,7 +367,7 @@ __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restr
     load_tile(A, S, lds, tid);
     __syncthreads();
     potrf64_lds(A, Tinv, tid, stamps);
-    store_tile(A, L, ldl, tid);
+    store_tile_lower(A, L, ldl, tid);
     store_inv(Tinv, Linv, tid);
     __syncthreads();
     if (tid == 0) stamps[11] = (long long)__builtin_amdgcn_s_memtime();
@@ -280,7 +382,7 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
     load_tile(A, S, lds, tid);
     __syncthreads();
     const bool bad = potrf64_lds(A, Tinv, tid);
-    store_tile(A, L, ldl, tid);
+    store_tile_lower(A, L, ldl, tid);
     store_inv(Tinv, Linv, tid);
     if (bad && tid == 0) atomicOr(info, 1);
 }
@@ -317,8 +419,10 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
     if (i != j) load_tile(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
     __syncthreads();
-    tri_solve_fwd(Ti, Tl, Tinv, wave, lane);             // L_ik = A_ik L_kk^-T
-    if (i != j) tri_solve_fwd(Tj, Tl, Tinv, wave, lane);  // L_jk
+    if (i != j)
+        tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
+    else
+        tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
     __syncthreads();
     if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
     // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
@@ -335,7 +439,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         }
         __syncthreads();
         const bool bad = potrf64_lds(Tl, Tinv, tid);
-        store_tile(Tl, L + (size_t)j * PB * ldl + (size_t)i * PB, ldl, tid);
+        store_tile_lower(Tl, L + (size_t)j * PB * ldl + (size_t)i * PB, ldl, tid);
         store_inv(Tinv, Linv + (size_t)(k + 1) * PB * PB, tid);
         if (bad && tid == 0) atomicOr(info, 1);
     } else {
@@ -364,6 +468,264 @@ __global__ __launch_bounds__(256) void chol_last_panel_kernel(const float* __res
     store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
 }
 
+
+// ---- agent-coherent tile movers for the persistent sweep ---------------------------------
+// The eight XCDs have private L2s; data handed from one workgroup to another inside a running
+// kernel must bypass them.  Agent-scope relaxed atomic accesses compile to sc1 loads/stores
+// (write-through / read from the coherence point), 8 bytes per lane, and need no L2
+// write-back or invalidate (a __threadfence here costs ~10 us: buffer_wbl2 of the whole L2).
+__device__ __forceinline__ float2 coh_load2(const float* p) {
+    const unsigned long long u =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+__device__ __forceinline__ void coh_store2(float* p, float a, float b) {
+    const unsigned long long u = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void load_tile_coh(float* T, const float* G, int ld, int tid) {
+    float2 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int e = tid + it * 256;
+        v[it] = coh_load2(G + (size_t)(e >> 5) * ld + (e & 31) * 2);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int e = tid + it * 256;
+        float* t = T + (e >> 5) * PLD + (e & 31) * 2;
+        t[0] = v[it].x; t[1] = v[it].y;
+    }
+}
+template <bool LOWER>
+__device__ __forceinline__ void store_tile_coh(const float* T, float* G, int ld, int tid) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int e = tid + it * 256;
+        const int c = e >> 5, r2 = (e & 31) * 2;
+        const float* t = T + c * PLD + r2;
+        coh_store2(G + (size_t)c * ld + r2, (!LOWER || r2 >= c) ? t[0] : 0.f, (!LOWER || r2 + 1 >= c) ? t[1] : 0.f);
+    }
+}
+__device__ __forceinline__ void load_inv_coh(float* Tinv, const float* G, int tid) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        const int e = (tid * 2 + h2) * 2;  // float index of a pair
+        const float2 v = coh_load2(G + e);
+        const int p = e >> 8, c = (e >> 4) & 15, r = e & 15;
+        Tinv[p * 16 * ILD + c * ILD + r] = v.x;
+        Tinv[p * 16 * ILD + c * ILD + r + 1] = v.y;
+    }
+}
+__device__ __forceinline__ void store_inv_coh(const float* Tinv, float* G, int tid) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        const int e = (tid * 2 + h2) * 2;
+        const int p = e >> 8, c = (e >> 4) & 15, r = e & 15;
+        coh_store2(G + e, Tinv[p * 16 * ILD + c * ILD + r], Tinv[p * 16 * ILD + c * ILD + r + 1]);
+    }
+}
+
+// ---- the whole sweep as ONE persistent launch -------------------------------------------
+// Workgroup 0 is the chain: it keeps L_kk and its 16x16 inverses in LDS from one block step to
+// the next, forms L_{k+1,k}, updates the next diagonal tile and factors it, and never leaves
+// the CU.  The other workgroups ("helpers") do the trailing tiles of step k as soon as
+// ready[k] is published.  Cross-workgroup ordering goes through two counters per block step
+// in global memory:
+//   ready[k] = 1      L_kk and its inverses are in global memory          (chain -> helpers)
+//   done[k]  = H      every helper has applied step k to all of its tiles (helpers -> all)
+// Helper h needs done[k-1] == H before touching step k because the panel blocks it reads were
+// updated by other helpers in step k-1; the chain needs it for tiles (k+1,k) and (k+1,k+1).
+// While the chain factors the next diagonal tile (about 6 us) the helpers finish step k (about
+// 3 us at N = 256), so in steady state nobody waits.  All waits are bounded: a wait that
+// exceeds SWEEP_SPIN_LIMIT polls raises the abort flag, after which every wait falls through
+// (the result is then garbage and info bit 1 is set), so the grid always drains.
+// Requires gridDim.x <= number of CUs (one resident workgroup per CU).
+#define SWEEP_SPIN_LIMIT (1 << 22)
+
+__device__ __forceinline__ void sweep_wait(int* flag, int target, int* abort_flag, int* info, int tid) {
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SWEEP_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(info, 2);
+                break;
+            }
+        }
+    }
+    __syncthreads();  // the coherent loads that follow are issued after the flag was seen
+}
+// every thread's coherent stores have completed (vmcnt 0) before the flag moves
+__device__ __forceinline__ void sweep_signal_set(int* flag, int tid) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sweep_signal_add(int* flag, int tid) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void chol_sweep_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
+                                                         float* __restrict__ Linv, int mb, int rb, int idb0, int* info,
+                                                         int* sync, long long* dbg) {
+    __shared__ float Ti[PB * PLD];
+    __shared__ float Tj[PB * PLD];
+    __shared__ float Tl[PB * PLD];
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int H = gridDim.x - 1;
+    int* ready = sync;
+    int* done = sync + mb;
+    int* abort_flag = sync + 2 * mb;
+    const int r = wr * 32 + (lane & 31);
+
+#define SWEEP_STAMP(slot)                                                                      \
+    do {                                                                                       \
+        if (dbg && tid == 0) dbg[(slot)] = (long long)__builtin_amdgcn_s_memtime();            \
+    } while (0)
+#define SWEEP_RSTAMP(slot) /* 100 MHz clock shared by all XCDs (s_memtime is per XCD) */     \
+    do {                                                                                       \
+        if (dbg && tid == 0) dbg[(slot)] = (long long)__builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+    if (blockIdx.x == 0) {
+        // ---------------- chain ----------------
+        SWEEP_STAMP(0);
+        load_tile_coh(Tl, S, lds, tid);
+        __syncthreads();
+        bool bad = potrf64_lds(Tl, Tinv, tid);
+        store_tile_coh<true>(Tl, L, ldl, tid);
+        store_inv_coh(Tinv, Linv, tid);
+        sweep_signal_set(ready + 0, tid);
+        SWEEP_STAMP(1);
+        for (int k = 0; k + 1 < mb; k++) {
+            SWEEP_STAMP(8 + 8 * k + 0);
+            if (k >= 1) sweep_wait(done + (k - 1), H, abort_flag, info, tid);
+            SWEEP_STAMP(8 + 8 * k + 1);
+            const int i = k + 1;
+            // the next diagonal tile's coherent loads fly while the panel block is solved
+            const float* Sii = S + (size_t)i * PB * lds + (size_t)i * PB;
+            float sv[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                sv[q] = __hip_atomic_load(Sii + (size_t)c * lds + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            load_tile_coh(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
+            __syncthreads();
+            SWEEP_STAMP(8 + 8 * k + 2);
+            tri_solve_fwd(Ti, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_kk still in LDS
+            __syncthreads();
+            SWEEP_STAMP(8 + 8 * k + 3);
+            store_tile_coh<false>(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+            const f32x16 up = mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane);
+            __syncthreads();  // every wave is done reading Tl (L_kk) before it is overwritten
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                Tl[c * PLD + r] = sv[q] - up[q];
+            }
+            __syncthreads();
+            SWEEP_STAMP(8 + 8 * k + 4);
+            bad |= potrf64_lds(Tl, Tinv, tid);
+            SWEEP_STAMP(8 + 8 * k + 5);
+            store_tile_coh<true>(Tl, L + (size_t)i * PB * ldl + (size_t)i * PB, ldl, tid);
+            store_inv_coh(Tinv, Linv + (size_t)i * PB * PB, tid);
+            sweep_signal_set(ready + i, tid);
+            SWEEP_STAMP(8 + 8 * k + 6);
+            SWEEP_RSTAMP(1008 + k);
+        }
+        if (bad && tid == 0) atomicOr(info, 1);
+        return;
+    }
+
+    // ---------------- helpers ----------------
+    const int h = blockIdx.x - 1;
+    for (int k = 0; k < mb; k++) {
+        const int rr = mb - 1 - k, ntri = rr * (rr + 1) / 2;
+        const int ntiles = (rr > 0) ? ntri + rb * rr : rb;
+        if (h == 1) SWEEP_STAMP(256 + 8 * k + 0);
+        if (k >= 1) sweep_wait(done + (k - 1), H, abort_flag, info, tid);
+        if (h == 1) SWEEP_STAMP(256 + 8 * k + 1);
+        bool have_L = false;  // L_kk and its inverses are fetched after the first tile's own loads are in flight
+        for (int t0 = h; t0 < ntiles; t0 += H) {
+            int t = t0, i, j;
+            if (rr == 0) {  // last block column: only the extra row blocks' panel solve is left
+                i = mb + t;
+                __syncthreads();
+                load_tile_coh(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
+                if (!have_L) {
+                    sweep_wait(ready + k, 1, abort_flag, info, tid);
+                    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);  // write-once data: L2 is safe
+                    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
+                    have_L = true;
+                }
+                __syncthreads();
+                tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
+                __syncthreads();
+                store_tile_coh<false>(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+                continue;
+            }
+            if (t < ntri) {
+                int ii = 0;
+                while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+                i = k + 1 + ii;
+                j = k + 1 + (t - ii * (ii + 1) / 2);
+                if (i == k + 1) continue;  // (k+1,k+1) belongs to the chain
+            } else {
+                t -= ntri;
+                i = mb + t / rr;
+                j = k + 1 + t % rr;
+                if (i >= idb0 && i - idb0 > k) continue;  // identity block row: block (i,k) is still zero
+            }
+            __syncthreads();  // previous tile's readers of Ti/Tj are done
+            load_tile_coh(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
+            if (i != j) load_tile_coh(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
+            float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
+            float sv[16];  // the target tile's coherent loads fly during the panel solves
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                sv[q] = __hip_atomic_load(Sij + (size_t)c * lds + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!have_L) {
+                sweep_wait(ready + k, 1, abort_flag, info, tid);
+                // L_kk and its inverses are written once (by the chain, write-through) and first read after
+                // ready[k]: no XCD can hold a stale copy, so these go through the L2 -- 170 helpers
+                // pulling the same 20 KB past the L2 is a fabric hot spot (measured: 10 us per step)
+                load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
+                load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
+                have_L = true;
+                if (h == 1) SWEEP_STAMP(256 + 8 * k + 2);
+                if (k == 2 && h < 240) SWEEP_RSTAMP(768 + h);
+            }
+            __syncthreads();
+            if (i != j)
+                tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);
+            else
+                tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
+            __syncthreads();
+            if (j == k + 1) store_tile_coh<false>(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+            const float* Bj = (i != j) ? Tj : Ti;
+            const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                __hip_atomic_store(Sij + (size_t)c * lds + r, sv[q] - up[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (h == 1) SWEEP_STAMP(256 + 8 * k + 3);
+        if (k == 2 && h < 240) SWEEP_RSTAMP(512 + h);
+        if (k + 1 < mb) sweep_signal_add(done + k, tid);
+        if (h == 1) SWEEP_STAMP(256 + 8 * k + 4);
+    }
+}
+
 }  // namespace
 
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps) {
@@ -375,6 +737,17 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int mb = m_pad / PB;
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
     const int idb0 = mb + n_pad / PB;
+    if (f->sweep_mode == 1) {
+        // one persistent launch; the grid must be co-resident (<= one workgroup per CU)
+        const int r0 = mb - 1;
+        const int tiles0 = r0 > 0 ? r0 * (r0 + 1) / 2 + rb * r0 : rb;
+        int helpers = tiles0 < f->num_cus - 1 ? tiles0 : f->num_cus - 1;
+        if (helpers < 1) helpers = 1;
+        (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * (2 * mb + 4), f->stream);
+        hipLaunchKernelGGL(chol_sweep_kernel, dim3(1 + helpers), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb, rb,
+                           idb0, f->info, f->sweep_sync, f->sweep_dbg);
+        return;
+    }
     hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info);
     for (int k = 0; k + 1 < mb; k++) {
         const int r = mb - 1 - k;

@@ -89,6 +89,10 @@ struct ekfvio_filter {
     float* Laug = nullptr;
     int ld_aug = 0;            // m_cap + ldp + m_cap
     float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
+    int* sweep_sync = nullptr; // [2*m_cap/64 + 4] ready/done counters + abort flag of the persistent sweep
+    int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
+    int num_cus = 0;
+    long long* sweep_dbg = nullptr;  // [512] s_memtime stamps of the persistent sweep (diagnostic; null = off)
     float* Km = nullptr;       // [ldp*m_cap]  Sigma H^T, solved in place into the Kalman gain
     float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
     float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
@@ -114,7 +118,7 @@ struct ekfvio_filter {
     double t_stamp = 0;
     bool have_stamp = false;
 
-    // --- hipGraph replay of device-resident sequences (two steps per graph: the mean
+    // --- hipGraph replay of device-resident sequences (an even number of steps per graph: the mean
     //     ping-pong mu <-> mu_next is back in its starting orientation after an even count) ---
     hipGraphExec_t step_graph = nullptr;
     int graph_N = -1, graph_m = -1, graph_frames = -1;

@@ -167,7 +167,8 @@ int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int
 int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int32_t M, int32_t N, int32_t K,
                            int32_t reps, int32_t variant, double* mean_us);
 /* Diagnostic: s_memtime stamps of the phases of one 64x64 diagonal-block factorisation. */
-int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[12]);
+int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[80]);
+int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t stamps[1024]);
 int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
                                float* L_out, float* X_out, int32_t* info);
 

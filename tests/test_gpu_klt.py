@@ -11,6 +11,8 @@ from PIL import Image
 from ekf_vio_amd import EKFVIO, KLTTracker, TightlyCoupledEKF, capi, EkfvioError
 from oracle import KltFrame, OracleFilter, klt_track
 
+from _scatter import backward_yardstick
+
 pytestmark = pytest.mark.gpu
 IMG = os.path.join(os.path.dirname(__file__), "golden", "images")
 K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)  # fx=fy=500
@@ -133,9 +135,14 @@ def test_config1_klt_plus_64_landmark_update():
     assert np.array_equal(sg["last_klt"], so["last_klt"])           # KLT results bit-exact through the ABI
     eg = np.abs(sg["base_mu"].astype(np.float64) - s64["base_mu"]).max()
     eo = np.abs(so["base_mu"].astype(np.float64) - s64["base_mu"]).max()
-    assert eg <= 12 * eo + 2e-5, (eg, eo)   # first update from the raw prior (see test_gpu_parity)
+    # first update from the raw prior (cond(S) = 1.6e6): the HIP result must lie within what an
+    # 8-ulp componentwise backward error on S and Sigma H^T explains (tests/_scatter.py; one ulp
+    # already moves the exact base state by 2e-4 here, the fp32 oracle lands at 5e-5..9e-5)
+    yard = backward_yardstick(st, z, R, passed.astype(np.uint8), s64, c=8.0)
+    assert eo <= yard["mu"]
+    assert eg <= yard["mu"] + 2e-5, (eg, eo, yard)
     rel = lambda x, y: np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y)
-    assert rel(sg["Sigma"], s64["Sigma"]) <= 4 * rel(so["Sigma"], s64["Sigma"]) + 2e-6
+    assert rel(sg["Sigma"], s64["Sigma"]) <= yard["sig"] + 4 * rel(so["Sigma"], s64["Sigma"]) + 2e-6, yard
     od = v.odometry()
     assert od["position"].shape == (3,) and abs(np.linalg.norm(od["orientation_wxyz"]) - 1) < 1e-6
     assert v.points().shape == (64, 3)

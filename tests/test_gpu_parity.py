@@ -23,10 +23,13 @@ from ekf_vio_amd import EkfvioError, TightlyCoupledEKF, capi
 from ekf_vio_amd.sim import Scenario
 from oracle import OracleFilter
 
+from _scatter import backward_yardstick, fp32_scatter
+
 pytestmark = pytest.mark.gpu
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
 UV3 = [[0.1, 0.1], [-0.1, -0.1], [0.1, -0.1]]
+BACKWARD_ULPS = 8.0  # first (ill-conditioned) update: allowed componentwise backward error, in fp32 ulp
 ACC_FACTOR = 4.0   # HIP forward error vs fp64 may be at most 4x the fp32 oracle's (measured <= ~3x)
 MU_FLOOR = 2e-5
 SIG_FLOOR = 2e-6
@@ -203,6 +206,9 @@ def test_teacher_forced_process_bit_exact_and_update_within_fp64_yardstick(N, st
         assert np.array_equal(sg["del_flag"], s32["del_flag"]) and np.array_equal(sg["last_klt"], s32["last_klt"])
         assert abs(np.linalg.norm(sg["base_mu"][3:7]) - 1) < 1e-6
         D = E0 if s == 0 else E
+        if s == 0:
+            scat0 = fp32_scatter(st, z, R, p, s64)
+            yard0 = backward_yardstick(st, z, R, p, s64, c=BACKWARD_ULPS)
         D["mu_gpu"] = max(D["mu_gpu"], maxabs(sg["base_mu"], s64["base_mu"]))
         D["mu_o32"] = max(D["mu_o32"], maxabs(s32["base_mu"], s64["base_mu"]))
         D["feat_gpu"] = max(D["feat_gpu"], maxabs(sg["feat_mu"], s64["feat_mu"]))
@@ -219,12 +225,17 @@ def test_teacher_forced_process_bit_exact_and_update_within_fp64_yardstick(N, st
     assert E["feat_gpu"] <= ACC_FACTOR * E["feat_o32"] + MU_FLOOR, E
     assert E["sig_gpu"] <= ACC_FACTOR * E["sig_o32"] + SIG_FLOOR, E
     # The very first update starts from the raw prior (velocity variance 30, inverse-depth
-    # variance 100 against R = 1e-5): cond(S) ~ 2.4e6 at N = 100, where fp32 LAPACK
-    # Cholesky, LDL^T and blocked variants of the same solve scatter over 4e-4 .. 8e-3 in the
-    # base state (scripts in DESIGN.md "Parity").  Hold HIP to 12x the oracle there.
-    assert E0["mu_gpu"] <= 12 * E0["mu_o32"] + MU_FLOOR, E0
-    assert E0["feat_gpu"] <= 12 * E0["feat_o32"] + MU_FLOOR, E0
-    assert E0["sig_gpu"] <= ACC_FACTOR * E0["sig_o32"] + SIG_FLOOR, E0
+    # variance 100 against R = 1e-5): cond(S) ~ 2.4e6 at N = 100, and ONE ulp of fp32 noise on S
+    # moves the exact answer by ~2e-4 in the base state; the reference's own fp32 arithmetic moves
+    # by up to 1e-3 when only the landmark order changes (tests/_scatter.py).  A single oracle
+    # run is therefore no yardstick for this step: the HIP result must lie within what a
+    # componentwise backward error of BACKWARD_ULPS ulp on S and Sigma H^T explains (the
+    # textbook bound for a Cholesky solve of this size is m ulp, m = 2N).
+    _report("teacher_forced_update N=%d first step: fp32 scatter over orderings" % N, scat0)
+    _report("teacher_forced_update N=%d first step: %g-ulp backward-error yardstick" % (N, BACKWARD_ULPS), yard0)
+    assert E0["mu_gpu"] <= yard0["mu"] + MU_FLOOR, (E0, yard0)
+    assert E0["feat_gpu"] <= yard0["feat"] + MU_FLOOR, (E0, yard0)
+    assert E0["sig_gpu"] <= yard0["sig"] + ACC_FACTOR * E0["sig_o32"] + SIG_FLOOR, (E0, yard0)
     g.close()
 
 
@@ -354,3 +365,28 @@ def test_dense_predict_matches_structured():
     assert np.array_equal(sa["base_mu"], sb["base_mu"]) and np.array_equal(sa["feat_mu"], sb["feat_mu"])
     assert relf(sb["Sigma"], sa["Sigma"]) < 2e-6
     a.close(), b.close()
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_per_call_bits():
+    """ekfvio_run_uploaded (hipGraph replay + eager remainder, frame counter on the device) against
+    one ekfvio_process + ekfvio_update per frame with host buffers: same kernels, same bits."""
+    N, frames = 30, 11
+    sc = Scenario(N, seed=5)
+    fr = list(sc.frames(frames))
+    z, R, p = (np.stack([f[i] for f in fr]) for i in range(3))
+    a = TightlyCoupledEKF(max_features=N)
+    a.addNewFeatures(sc.initial_features())
+    a.upload_measurements(z, R, p)
+    a.run_uploaded(0, frames, sc.dt)
+    a.synchronize()
+    b = TightlyCoupledEKF(max_features=N)
+    b.addNewFeatures(sc.initial_features())
+    for i in range(frames):
+        b.process(sc.dt)
+        b.updateWithFeaturePositions(z[i], R[i], p[i])
+    sa, sb = a.get_state(), b.get_state()
+    for key in ("base_mu", "feat_mu", "last_klt", "del_flag", "Sigma"):
+        assert np.array_equal(sa[key], sb[key]), key
+    a.close()
+    b.close()

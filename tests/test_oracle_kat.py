@@ -172,3 +172,42 @@ def test_simulation_invariants(N, ds, vel, om, tf, dtype):
     if tf > 1:  # the filter must have inferred the motion (it starts at zero velocity)
         assert np.abs(st["base_mu"][0:3] - sc.pos).max() < 0.02
         assert np.abs(st["base_mu"][7:10] - sc.vel).max() < 0.02
+
+
+def test_fp32_scatter_yardstick_first_update():
+    """tests/_scatter.py: the identity ordering is one of the orderings (so the scatter bounds the
+    plain oracle error from above) and un-permuting is exact (fp64 on fp64 gives ~0)."""
+    from _scatter import fp32_scatter, _perm_state
+    from ekf_vio_amd.sim import Scenario
+    N = 30
+    sc = Scenario(N, seed=0, dt=0.05)
+    o32, o64 = OracleFilter(np.float32), OracleFilter(np.float64)
+    o32.add_new_features(sc.initial_features())
+    z, R, p = next(iter(sc.frames(1)))
+    o32.process(sc.dt)
+    st = o32.get_state()
+    o64.set_state(st)
+    o64.update(z, R, p)
+    s64 = o64.get_state()
+    one, six = fp32_scatter(st, z, R, p, s64, nperm=1), fp32_scatter(st, z, R, p, s64, nperm=6)
+    assert all(six[k] >= one[k] for k in one) and 1e-7 < six["mu"] < 1e-2
+    # permutation round trip in fp64: the same answer except for which triangle of the (only
+    # fp32-symmetric) Sigma ends up in S^T's lower triangle, a 1e-6-level input difference that is
+    # three orders below the fp32 scatter this yardstick measures
+    perm = np.random.default_rng(1).permutation(N)
+    sp, idx = _perm_state(st, perm)
+    q = OracleFilter(np.float64)
+    q.set_state(sp)
+    q.update(z[perm], R[perm], p[perm])
+    out = q.get_state()
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(N)
+    assert np.abs(out["feat_mu"][inv] - s64["feat_mu"]).max() < 1e-4
+    assert np.abs(out["base_mu"] - s64["base_mu"]).max() < 1e-4
+    # the backward-error yardstick's fp64 restatement of the update is the oracle's: zero
+    # perturbation reproduces the fp64 oracle state, and the yardstick grows with the ulp budget
+    from _scatter import backward_yardstick
+    y0 = backward_yardstick(st, z, R, p, s64, c=0.0, trials=1)
+    assert y0["mu"] < 1e-10 and y0["feat"] < 1e-10 and y0["sig"] < 1e-12
+    y1, y8 = backward_yardstick(st, z, R, p, s64, c=1.0), backward_yardstick(st, z, R, p, s64, c=8.0)
+    assert 0 < y1["mu"] < y8["mu"] < 0.05
