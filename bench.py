@@ -173,7 +173,7 @@ def main():
         flops_per_launch = ge["flops"] / max(ge["launches"], 1)
         avg_ms = ge["ms"] / max(ge["launches"], 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        extra["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel<true,1,1|2> (P-update GEMMs: Sigma - K W, T + G K^T)",
+        extra["roofline"] = {"bound": "mfma", "kernel": "gemm16_kernel<BM,2,1|2> (P-update GEMMs: Sigma - K W, T + G K^T; BM x 64 tiles, BM chosen by shape)",
                              "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                              "flops_per_launch": flops_per_launch, "avg_launch_us": avg_ms * 1e3,

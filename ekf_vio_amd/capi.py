@@ -75,7 +75,7 @@ def load(build_if_missing=True):
         "ekfvio_synchronize": [vp], "ekfvio_profile_enable": [vp, i32], "ekfvio_profile_reset": [vp],
         "ekfvio_profile_count": [], "ekfvio_profile_name": [i32],
         "ekfvio_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
-        "ekfvio_test_gemm": [vp, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32],
+        "ekfvio_test_gemm": [vp, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, i32],
         "ekfvio_test_cholesky_solve": [vp, i32, i32, fp, fp, fp, fp, ip],
         "ekfvio_test_potrf_stamps": [vp, C.POINTER(C.c_int64)],
         "ekfvio_test_sweep_stamps": [vp, C.c_int, C.POINTER(C.c_int64)],

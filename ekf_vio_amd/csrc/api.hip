@@ -483,12 +483,12 @@ int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t*
 
 // ---- raw kernels for unit tests -------------------------------------------------------
 int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
-                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc) {
+                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc, int32_t variant) {
     if (!f || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
-    // device copies padded to the kernel's contract (64-row/col slack, K to 16, zero fill);
+    // device copies padded to the kernels' contract (64-row/col slack, K to 64, zero fill);
     // packed on the host so that only flat copies are issued
-    const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 32);
+    const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 64);
     const int brows = transB ? Np : Kp, bcols = transB ? Kp : Np;
     std::vector<float> hA((size_t)Mp * Kp, 0.f), hB((size_t)brows * bcols, 0.f), hC((size_t)Mp * Np, 0.f);
     for (int k = 0; k < K; k++)
@@ -504,7 +504,7 @@ int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int
     HIPC(f, hipMemcpyAsync(dA, hA.data(), sizeof(float) * hA.size(), hipMemcpyHostToDevice, f->stream));
     HIPC(f, hipMemcpyAsync(dB, hB.data(), sizeof(float) * hB.size(), hipMemcpyHostToDevice, f->stream));
     HIPC(f, hipMemcpyAsync(dC, hC.data(), sizeof(float) * hC.size(), hipMemcpyHostToDevice, f->stream));
-    launch_gemm(f->stream, transB, M, N, Kp, alpha, dA, Mp, dB, brows, beta, dC, Mp, dC, Mp, 0);
+    launch_gemm_variant(f->stream, variant, transB, M, N, Kp, alpha, dA, Mp, dB, brows, beta, dC, Mp, dC, Mp, 0, 0);
     HIPC(f, hipMemcpyAsync(hC.data(), dC, sizeof(float) * hC.size(), hipMemcpyDeviceToHost, f->stream));
     HIPC(f, hipStreamSynchronize(f->stream));
     for (int j = 0; j < N; j++)
@@ -522,7 +522,7 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
                            int32_t reps, int32_t variant, double* mean_us) {
     if (!f || M <= 0 || N <= 0 || K <= 0 || reps <= 0 || !mean_us) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
-    const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 32);
+    const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 64);
     const int brows = transB ? Np : Kp, bcols = transB ? Kp : Np;
     std::vector<float> hA((size_t)Mp * Kp), hB((size_t)brows * bcols), hC((size_t)Mp * Np);
     uint32_t st = 12345u;

@@ -22,6 +22,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic cycle stamps (s_memtime) of workgroup (0,0), wave 0; nullptr in production.
 __device__ long long* g_gemm_stamps = nullptr;
@@ -332,13 +333,296 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     GSTAMP(38);
 }
 
-static void launch_gemm_cfg(hipStream_t s, int groups, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+
+// ---------------------------------------------------------------------------------------
+// Second tiling, for A * B^T at the filter's sizes, where a launch is ONE wave of workgroups and
+// its duration is one workgroup's latency: BMt x 64 tiles with BMt in {32, 48, 64} chosen so that
+// the tile count just fits the CUs (790 x 790: 221 tiles of 48 x 64 instead of 169 of 64 x 64,
+// i.e. 3/4 of the MFMA work on the critical path).  Each wavefront owns 16 columns and all BMt
+// rows: BMt/16 independent 16x16 accumulators on v_mfma_f32_16x16x4_f32 (32-cycle issue, 40-cycle
+// dependent latency: two or three independent chains keep the pipe full).  K-tiles are 64 deep
+// (half the barriers of the 32-deep kernel above), LDS tiles are [k][row] with a row stride of
+// 16 (mod 32) floats, which makes the operand read (16 lanes -> consecutive rows, next 16 lanes
+// -> next k) conflict-free, filled by one ds_write_b128 per global float4.  Operand fragments
+// are read two k-steps ahead of their MFMAs; staging of tile t+1 and the global loads of tile
+// t+2 are issued at the top of tile t.
+// Workgroups are dealt round-robin to the 8 XCDs; the 1-D block index is remapped so that every
+// XCD works on a contiguous run of tiles and re-reads the same operand panels from ITS L2.
+template <int BMt, int WPS, int EPI>
+__global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
+                                                     const float* __restrict__ B, int ldb, float beta, const float* Cin,
+                                                     int ldcin, float* C, int ldc, int flush, int lowerB, GemmEpi epi,
+                                                     int tiles_x) {
+    constexpr int RB = BMt / 16;                            // 16-row blocks per wavefront
+    constexpr int SA = (BMt % 32 == 16) ? BMt : BMt + 16;   // LDS row strides, both = 16 mod 32
+    constexpr int SB = 80;
+    constexpr int BKK = 64;
+    constexpr int NT = 256 * WPS;                           // threads; WPS = wavefronts per SIMD
+    constexpr int AVT = BKK * BMt / 4;                      // float4 per K-tile of A
+    constexpr int AV = (AVT + NT - 1) / NT;                 // ... per thread (the last one may be partial)
+    constexpr int BV = BKK * 64 / 4 / NT;                   // of B: 4 (256 threads) or 2 (512)
+    constexpr int BKS = NT / 16;                            // k-rows of B covered by one float4 per thread
+    constexpr int NS = BKK / 4 / WPS;                       // k-steps per wavefront per K-tile
+    __shared__ __attribute__((aligned(16))) float As[2][BKK * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKK * SB];
+
+    // XCD-aware tile order (bijective for any grid size)
+    const int nwg = gridDim.x;
+    const int bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
+    const int swz = xcd * bq + min(xcd, br) + (blockIdx.x >> 3);
+    const int i0 = (swz % tiles_x) * BMt;
+    const int j0 = (swz / tiles_x) * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) & 3;   // 16-column slice of the tile
+    const int kg = tid >> 8;           // WPS = 2: wavefronts 4-7 take the odd k-steps of every K-tile
+    const int li = lane & 15, g = lane >> 4;
+    const int Mread = (M + 63) & ~63;  // readable rows of A (contract)
+
+    const int kbeg = lowerB ? min(j0, K) : 0;
+    const int KT = (K - kbeg) / BKK;
+
+    // staging coordinates (scalars, not arrays: hipcc sends a loop-carried float4 array to scratch)
+#define G16_ACOORD(u)                                                                       \
+    const int ea##u = min(tid + NT * u, AVT - 1);                                           \
+    const float* ag##u = A + (size_t)(kbeg + ea##u / (BMt / 4)) * lda + min(i0 + (ea##u % (BMt / 4)) * 4, Mread - 4); \
+    const int al##u = (ea##u / (BMt / 4)) * SA + (ea##u % (BMt / 4)) * 4;
+    G16_ACOORD(0) G16_ACOORD(1) G16_ACOORD(2) G16_ACOORD(3)
+#undef G16_ACOORD
+    const float* bg = B + (size_t)(kbeg + (tid >> 4)) * ldb + j0 + (tid & 15) * 4;  // k-rows tid>>4, + BKS, ...
+    const int bl = (tid >> 4) * SB + (tid & 15) * 4;
+    const size_t a_step = (size_t)BKK * lda, b_step = (size_t)BKK * ldb;
+    static_assert((BV == 4 || BV == 2) && AV >= 1 && AV <= 4, "staging is written for 1..4 float4 of A and 2 or 4 of B per thread");
+
+    f32x4 acc[RB];
+#pragma unroll
+    for (int a = 0; a < RB; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the C tile this wave will update is requested first (see the 32x32 kernel)
+    float cpre[RB][4];
+#pragma unroll
+    for (int a = 0; a < RB; a++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int i = i0 + 16 * a + li, j = j0 + 16 * wave + 4 * g + v;
+            cpre[a][v] = (beta != 0.f && i < M && j < N) ? Cin[(size_t)j * ldcin + i] : 0.f;
+        }
+
+    // Two staging register sets, X and Y, alternate between iterations (tile t+1 sits in one while
+    // tile t+2 is loaded into the other).  With a single set hipcc loads into fresh registers and
+    // copies them back at the loop edge, which parks a full memory round trip behind every K-tile.
+    float4 Xa0, Xa1, Xa2, Xa3, Xb0, Xb1, Xb2, Xb3, Ya0, Ya1, Ya2, Ya3, Yb0, Yb1, Yb2, Yb3;
+    Xa0 = Xa1 = Xa2 = Xa3 = Xb0 = Xb1 = Xb2 = Xb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Ya0 = Ya1 = Ya2 = Ya3 = Yb0 = Yb1 = Yb2 = Yb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define G16_LOAD(S, kt)                                                                                \
+    do {                                                                                               \
+        const size_t ao_ = (size_t)(kt) * a_step;                                                      \
+        const float* bp_ = bg + (size_t)(kt) * b_step;                                                 \
+        S##a0 = *reinterpret_cast<const float4*>(ag0 + ao_);                                           \
+        if constexpr (AV > 1) S##a1 = *reinterpret_cast<const float4*>(ag1 + ao_);                     \
+        if constexpr (AV > 2) S##a2 = *reinterpret_cast<const float4*>(ag2 + ao_);                     \
+        if constexpr (AV > 3) S##a3 = *reinterpret_cast<const float4*>(ag3 + ao_);                     \
+        S##b0 = *reinterpret_cast<const float4*>(bp_);                                                 \
+        S##b1 = *reinterpret_cast<const float4*>(bp_ + (size_t)BKS * ldb);                             \
+        if constexpr (BV > 2) S##b2 = *reinterpret_cast<const float4*>(bp_ + (size_t)(2 * BKS) * ldb); \
+        if constexpr (BV > 2) S##b3 = *reinterpret_cast<const float4*>(bp_ + (size_t)(3 * BKS) * ldb); \
+    } while (0)
+#define G16_STAGE(S, buf)                                                                              \
+    do {                                                                                               \
+        *reinterpret_cast<float4*>(&As[buf][al0]) = S##a0; /* a clamped duplicate rewrites the same bytes */ \
+        if constexpr (AV > 1) *reinterpret_cast<float4*>(&As[buf][al1]) = S##a1;                       \
+        if constexpr (AV > 2) *reinterpret_cast<float4*>(&As[buf][al2]) = S##a2;                       \
+        if constexpr (AV > 3) *reinterpret_cast<float4*>(&As[buf][al3]) = S##a3;                       \
+        *reinterpret_cast<float4*>(&Bs[buf][bl]) = S##b0;                                              \
+        *reinterpret_cast<float4*>(&Bs[buf][bl + BKS * SB]) = S##b1;                                   \
+        if constexpr (BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 2 * BKS * SB]) = S##b2;         \
+        if constexpr (BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 3 * BKS * SB]) = S##b3;         \
+    } while (0)
+#define G16_FR(st, slot)                                                                  \
+    do {                                                                                  \
+        fb[slot] = pb[(4 * WPS * (st)) * SB];                                             \
+        _Pragma("unroll") for (int a = 0; a < RB; a++) fa[slot][a] = pa[(4 * WPS * (st)) * SA + 16 * a]; \
+    } while (0)
+    // one K-tile (LDS buffer `cur`): tile t+1 (register set S1, loaded an iteration ago) -> the other
+    // LDS buffer, whose readers all passed the barrier that ended tile t-1; request tile t+2 into S2;
+    // this wavefront's k-steps (every WPS-th), operand fragments read two steps ahead
+#define G16_TILE(cur, S1, S2, tnext)                                                      \
+    do {                                                                                  \
+        const float* pa = &As[cur][(g + 4 * kg) * SA + li];                               \
+        const float* pb = &Bs[cur][(g + 4 * kg) * SB + 16 * wave + li];                   \
+        G16_FR(0, 0);                                                                     \
+        G16_FR(1, 1);                                                                     \
+        G16_STAGE(S1, (cur) ^ 1);                                                         \
+        G16_LOAD(S2, tnext);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        _Pragma("unroll") for (int st = 0; st < NS; st++) {                               \
+            if (st + 2 < NS) G16_FR(st + 2, (st + 2) % 3);                                \
+            _Pragma("unroll") for (int a = 0; a < RB; a++)                                \
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[st % 3], fa[st % 3][a], acc[a], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+        __syncthreads();                                                                  \
+    } while (0)
+
+    if (KT > 0) {
+        const int kl = KT - 1;
+        G16_LOAD(X, 0);
+        G16_STAGE(X, 0);
+        G16_LOAD(X, min(1, kl));
+        __syncthreads();
+        float fa[3][RB], fb[3];
+        int t = 0;
+        for (; t + 1 < KT; t += 2) {
+            G16_TILE(0, X, Y, min(t + 2, kl));
+            G16_TILE(1, Y, X, min(t + 3, kl));
+        }
+        if (t < KT) G16_TILE(0, X, Y, kl);
+    }
+#undef G16_TILE
+#undef G16_FR
+#undef G16_LOAD
+#undef G16_STAGE
+    if constexpr (WPS > 1) {
+        // sum the two k-interleaved partial accumulators through LDS (the staging buffers are free:
+        // every wavefront passed the barrier that ended the last K-tile)
+        float* red = &As[0][0];
+        static_assert(2 * BKK * SA >= RB * 4 * 256, "reduction scratch");
+        if (kg == 1) {
+#pragma unroll
+            for (int a = 0; a < RB; a++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) red[(a * 4 + v) * 256 + (tid & 255)] = acc[a][v];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int a = 0; a < RB; a++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[a][v] += red[(a * 4 + v) * 256 + tid];
+    }
+
+    // epilogue: lane -> row (contiguous in memory), register -> column
+    float vout[RB][4];
+#pragma unroll
+    for (int a = 0; a < RB; a++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float x = alpha * acc[a][v];
+            x = x + beta * cpre[a][v];
+            if (flush) x = (fabsf(x) > EKF_FLUSH_THRESH) ? x : 0.f;
+            vout[a][v] = x;
+        }
+    const int jb = j0 + 16 * wave + 4 * g;
+    if (EPI == 1) {
+        // G(i,q) = (K R)(i,q) - T(i, idx[q]) for the measured columns of this tile (A is K)
+        int qv[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) qv[v] = epi.inv_idx[min(jb + v, N - 1)];
+        float kq[RB][4], kp[RB][4];
+#pragma unroll
+        for (int a = 0; a < RB; a++) {
+            const int ic = min(i0 + 16 * a + li, M - 1);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int q = max(qv[v], 0);
+                kq[a][v] = A[(size_t)q * lda + ic] * epi.Rm[2 * q];
+                kp[a][v] = A[(size_t)(q ^ 1) * lda + ic] * epi.Rm[2 * q + 1];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < RB; a++) {
+            const int i = i0 + 16 * a + li;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int q = qv[v];
+                const float kr = ((q ^ 1) < q) ? (kp[a][v] + kq[a][v]) : (kq[a][v] + kp[a][v]);  // ascending measurement index
+                if (q >= 0 && jb + v < N && i < M) epi.G[(size_t)q * epi.ldg + i] = kr - vout[a][v];
+            }
+        }
+    }
+    if (EPI == 2 && i0 == 0 && j0 == 0) {
+        // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
+        __shared__ float s_q[4];
+        for (int e = threadIdx.x; e < epi.n; e += 256) {
+            const float v = epi.mu[e] + epi.Pcol[e];
+            if (e >= 3 && e <= 6) s_q[e - 3] = v;
+            else epi.mu[e] = v;
+            epi.Pcol[e] = 0.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): s_q written
+        __builtin_amdgcn_s_barrier();        // only the epilogue's 256 threads are left (WPS = 2: the others returned)
+        if (threadIdx.x < 4) {
+            const float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
+            epi.mu[3 + threadIdx.x] = s_q[threadIdx.x] / qn;
+        }
+        if (threadIdx.x == 0 && epi.frame_counter) {
+            const int fi = *epi.frame_counter + 1;
+            *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < RB; a++) {
+        const int i = i0 + 16 * a + li;
+        if (i < M) {
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                if (jb + v < N) C[(size_t)(jb + v) * ldc + i] = vout[a][v];
+        }
+    }
+}
+
+// cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
+// (512 threads); +100 = the same with 256 threads
+static void launch_gemm_cfg(hipStream_t s, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                             const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                             int lowerB, const GemmEpi* epi) {
     if (M <= 0 || N <= 0 || K <= 0) return;
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
     GemmEpi e;
     if (epi) e = *epi;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0)
+            cus = 256;
+    }
+    const int ty = (N + 63) / 64;
+    if (cfg == 0) {
+        cfg = 1;
+        if (transB && K % 64 == 0) {
+            // latency regime: the smallest tile height whose grid is still a single wave of workgroups
+            for (int bm : {32, 48, 64}) {
+                if (((M + bm - 1) / bm) * ty <= cus) {
+                    cfg = bm;
+                    break;
+                }
+            }
+        }
+    }
+    if (cfg >= 32) {
+        const int wps = cfg >= 100 ? 1 : 2;  // 132 / 148 / 164: one wavefront per SIMD (micro-benchmark only)
+        const int bm = cfg % 100;
+        const int tx = (M + bm - 1) / bm;
+        dim3 grid(tx * ty);
+#define GEMM16_GO(BMv, W, EP)                                                                                           \
+    hipLaunchKernelGGL((gemm16_kernel<BMv, W, EP>), grid, dim3(256 * W), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, \
+                       ldc, flush, lowerB, e, tx)
+#define GEMM16_BM(W, EP)                          \
+    do {                                          \
+        if (bm == 32) GEMM16_GO(32, W, EP);       \
+        else if (bm == 48) GEMM16_GO(48, W, EP);  \
+        else GEMM16_GO(64, W, EP);                \
+    } while (0)
+        if (e.mode == 1) GEMM16_BM(2, 1);
+        else if (e.mode == 2) GEMM16_BM(2, 2);
+        else if (wps == 2) GEMM16_BM(2, 0);
+        else GEMM16_BM(1, 0);
+#undef GEMM16_BM
+#undef GEMM16_GO
+        return;
+    }
+    const int groups = cfg == 2 ? 2 : 1;
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
 #define GEMM_GO(TB, G, EP)                                                                                             \
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G, EP>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
                        Cin, ldcin, C, ldc, flush, lowerB, e)
@@ -356,18 +640,19 @@ static void launch_gemm_cfg(hipStream_t s, int groups, int transB, int M, int N,
 #undef GEMM_GO
 }
 
-// Production configuration: 256 threads.  (GROUPS = 2 is kept for the micro-benchmark.)
 void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                  int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB,
                  const GemmEpi* epi) {
-    launch_gemm_cfg(s, 1, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, epi);
+    launch_gemm_cfg(s, 0, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, epi);
 }
 
+// variant: 0 = production choice, 1 = 64x64 tiles / 256 threads, 2 = 64x64 / 512 threads, 32 / 48 / 64 = BM of gemm16_kernel
 void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                          int lowerB) {
-    launch_gemm_cfg(s, variant == 2 ? 2 : 1, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB,
-                    nullptr);
+    if (variant >= 32 && (!transB || K % 64 != 0)) variant = 1;
+    if (variant >= 32 && variant % 100 != 32 && variant % 100 != 48 && variant % 100 != 64) variant = 0;
+    launch_gemm_cfg(s, variant, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, nullptr);
 }
 
 void gemm_set_stamp_buffer(long long* d_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &d_buf, sizeof(d_buf)); }

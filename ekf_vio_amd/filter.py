@@ -182,7 +182,7 @@ class TightlyCoupledEKF:
         return out
 
     # ---- raw kernels -------------------------------------------------------------------
-    def test_gemm(self, A, B, C0, alpha=1.0, beta=0.0, transB=True):
+    def test_gemm(self, A, B, C0, alpha=1.0, beta=0.0, transB=True, variant=0):
         """C = beta*C0 + alpha * A @ (B.T if transB else B); arrays are numpy [row, col]."""
         A = np.asarray(A, np.float32)
         B = np.asarray(B, np.float32)
@@ -191,7 +191,7 @@ class TightlyCoupledEKF:
         Ac, Bc = np.array(A.T, order="C", copy=True), np.array(B.T, order="C", copy=True)  # column-major buffers
         Cc = np.array(np.asarray(C0, np.float32).T, order="C", copy=True)  # never alias the caller's C0
         self._chk(self.lib.ekfvio_test_gemm(self.h, int(transB), M, N, K, alpha, _fp(Ac), M, _fp(Bc), B.shape[0], beta,
-                                            _fp(Cc), M))
+                                            _fp(Cc), M, int(variant)))
         return Cc.T.copy()
 
     def test_cholesky_solve(self, S, Crhs):

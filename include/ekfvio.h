@@ -160,9 +160,10 @@ int ekfvio_profile_count(void);
 const char* ekfvio_profile_name(int32_t cls);
 int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t* launches, double* flops);
 
-/* Raw kernels for unit tests (column-major, device copies made internally). */
+/* Raw kernels for unit tests (column-major, device copies made internally).  variant: 0 = the
+ * production tile choice, 1 / 2 = 64x64 tiles with 256 / 512 threads, 32 / 48 / 64 = BM x 64 tiles. */
 int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
-                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc);
+                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc, int32_t variant);
 /* Mean time (us) of `reps` back-to-back GEMM launches at one shape, operands resident. */
 int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int32_t M, int32_t N, int32_t K,
                            int32_t reps, int32_t variant, double* mean_us);
