@@ -46,7 +46,8 @@ def build(force=False, verbose=False):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
                 and os.path.getmtime(obj) >= newest_hdr):
             continue
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + ["-c", "-o", obj, src]
+        extra = os.environ.get("EKFVIO_EXTRA_HIPCC_FLAGS", "").split()  # diagnostics, e.g. -DEKF_GEMM_STAMPS
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + extra + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
         jobs.append((cmd, subprocess.Popen(cmd)))

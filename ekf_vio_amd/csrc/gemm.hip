@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     constexpr int BV = BKK * 64 / 4 / NT;                   // of B: 4 (256 threads) or 2 (512)
     constexpr int BKS = NT / 16;                            // k-rows of B covered by one float4 per thread
     constexpr int NS = BKK / 4 / WPS;                       // k-steps per wavefront per K-tile
-    __shared__ __attribute__((aligned(16))) float As[2][BKK * SA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKK * SB];
+    __shared__ __attribute__((aligned(16))) float As[3][BKK * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[3][BKK * SB];
 
     // XCD-aware tile order (bijective for any grid size)
     const int nwg = gridDim.x;
@@ -373,6 +373,10 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     const int i0 = (swz % tiles_x) * BMt;
     const int j0 = (swz / tiles_x) * 64;
 
+#ifdef EKF_GEMM_STAMPS
+    long long* stamps_ = (blockIdx.x == 9 && threadIdx.x == 0) ? g_gemm_stamps : nullptr;
+#endif
+    GSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (tid >> 6) & 3;   // 16-column slice of the tile
     const int kg = tid >> 8;           // WPS = 2: wavefronts 4-7 take the odd k-steps of every K-tile
@@ -427,66 +431,149 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
         if constexpr (BV > 2) S##b2 = *reinterpret_cast<const float4*>(bp_ + (size_t)(2 * BKS) * ldb); \
         if constexpr (BV > 2) S##b3 = *reinterpret_cast<const float4*>(bp_ + (size_t)(3 * BKS) * ldb); \
     } while (0)
-#define G16_STAGE(S, buf)                                                                              \
+// item j of a K-tile's AV + BV float4 per thread: first the A pieces, then the B pieces
+#define G16_LOADI(S, j, kt)                                                                            \
+    do {                                                                                               \
+        const size_t ao_ = (size_t)(kt) * a_step;                                                      \
+        const float* bp_ = bg + (size_t)(kt) * b_step;                                                 \
+        if ((j) == 0) S##a0 = *reinterpret_cast<const float4*>(ag0 + ao_);                             \
+        if ((j) == 1 && AV > 1) S##a1 = *reinterpret_cast<const float4*>(ag1 + ao_);                   \
+        if ((j) == 2 && AV > 2) S##a2 = *reinterpret_cast<const float4*>(ag2 + ao_);                   \
+        if ((j) == 3 && AV > 3) S##a3 = *reinterpret_cast<const float4*>(ag3 + ao_);                   \
+        if ((j) == AV) S##b0 = *reinterpret_cast<const float4*>(bp_);                                  \
+        if ((j) == AV + 1) S##b1 = *reinterpret_cast<const float4*>(bp_ + (size_t)BKS * ldb);          \
+        if ((j) == AV + 2 && BV > 2) S##b2 = *reinterpret_cast<const float4*>(bp_ + (size_t)(2 * BKS) * ldb); \
+        if ((j) == AV + 3 && BV > 2) S##b3 = *reinterpret_cast<const float4*>(bp_ + (size_t)(3 * BKS) * ldb); \
+    } while (0)
+#define G16_STAGEI(S, j, buf)                                                                          \
+    do {                                                                                               \
+        if ((j) == 0) *reinterpret_cast<float4*>(&As[buf][al0]) = S##a0;                               \
+        if ((j) == 1 && AV > 1) *reinterpret_cast<float4*>(&As[buf][al1]) = S##a1;                     \
+        if ((j) == 2 && AV > 2) *reinterpret_cast<float4*>(&As[buf][al2]) = S##a2;                     \
+        if ((j) == 3 && AV > 3) *reinterpret_cast<float4*>(&As[buf][al3]) = S##a3;                     \
+        if ((j) == AV) *reinterpret_cast<float4*>(&Bs[buf][bl]) = S##b0;                               \
+        if ((j) == AV + 1) *reinterpret_cast<float4*>(&Bs[buf][bl + BKS * SB]) = S##b1;                \
+        if ((j) == AV + 2 && BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 2 * BKS * SB]) = S##b2;  \
+        if ((j) == AV + 3 && BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 3 * BKS * SB]) = S##b3;  \
+    } while (0)
+#define G16_STAGE_A(S, buf)                                                                            \
     do {                                                                                               \
         *reinterpret_cast<float4*>(&As[buf][al0]) = S##a0; /* a clamped duplicate rewrites the same bytes */ \
         if constexpr (AV > 1) *reinterpret_cast<float4*>(&As[buf][al1]) = S##a1;                       \
         if constexpr (AV > 2) *reinterpret_cast<float4*>(&As[buf][al2]) = S##a2;                       \
         if constexpr (AV > 3) *reinterpret_cast<float4*>(&As[buf][al3]) = S##a3;                       \
+    } while (0)
+#define G16_STAGE_B(S, buf)                                                                            \
+    do {                                                                                               \
         *reinterpret_cast<float4*>(&Bs[buf][bl]) = S##b0;                                              \
         *reinterpret_cast<float4*>(&Bs[buf][bl + BKS * SB]) = S##b1;                                   \
         if constexpr (BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 2 * BKS * SB]) = S##b2;         \
         if constexpr (BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 3 * BKS * SB]) = S##b3;         \
     } while (0)
-#define G16_FR(st, slot)                                                                  \
+#ifdef EKF_G16_ASM_MFMA
+#define G16_MFMA(c, b, a) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(b), "v"(a))
+#else
+#define G16_MFMA(c, b, a) c = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, c, 0, 0, 0)
+#endif
+// timing experiments only (results are wrong with any of these set): -DG16X_NOLOAD=1 ...
+#ifndef G16X_NOLOAD
+#define G16X_NOLOAD 0
+#endif
+#ifndef G16X_NOSTAGE
+#define G16X_NOSTAGE 0
+#endif
+#ifndef G16X_NOBAR
+#define G16X_NOBAR 0
+#endif
+#ifndef G16X_NOFR
+#define G16X_NOFR 0
+#endif
+#define G16_FR(P, st, slot)                                                               \
     do {                                                                                  \
-        fb[slot] = pb[(4 * WPS * (st)) * SB];                                             \
-        _Pragma("unroll") for (int a = 0; a < RB; a++) fa[slot][a] = pa[(4 * WPS * (st)) * SA + 16 * a]; \
+        if (G16X_NOFR) break;                                                             \
+        fb[slot] = P##b[(4 * WPS * (st)) * SB];                                           \
+        _Pragma("unroll") for (int a = 0; a < RB; a++) fa[slot][a] = P##a[(4 * WPS * (st)) * SA + 16 * a]; \
     } while (0)
-    // one K-tile (LDS buffer `cur`): tile t+1 (register set S1, loaded an iteration ago) -> the other
-    // LDS buffer, whose readers all passed the barrier that ended tile t-1; request tile t+2 into S2;
-    // this wavefront's k-steps (every WPS-th), operand fragments read two steps ahead
-#define G16_TILE(cur, S1, S2, tnext)                                                      \
+    // One K-tile t out of LDS buffer t % 3.  Per wavefront NS k-steps (every WPS-th of the tile); a
+    // step's operand fragments are read two steps ahead, for steps 0 and 1 already during the
+    // previous tile.  Around the MFMAs of
+    //   steps 0..BAR-1  one global load of tile t+2 (register set S2) and one LDS write of tile t+1
+    //               (register set S1, loaded a whole tile ago, to buffer (t+1) % 3) per step,
+    //   step BAR    the one barrier of the tile: tile t+1 is visible from here on, and every wavefront
+    //               is done with buffer (t-1) % 3, the target of the NEXT tile's staging,
+    //   steps NS-2, NS-1  the first two fragment sets of tile t+1 are fetched,
+    // so no LDS or memory latency is left between the last MFMA of one tile and the first of the next.
+#define G16_TILE(S1, S2, tcur)                                                            \
     do {                                                                                  \
-        const float* pa = &As[cur][(g + 4 * kg) * SA + li];                               \
-        const float* pb = &Bs[cur][(g + 4 * kg) * SB + 16 * wave + li];                   \
-        G16_FR(0, 0);                                                                     \
-        G16_FR(1, 1);                                                                     \
-        G16_STAGE(S1, (cur) ^ 1);                                                         \
-        G16_LOAD(S2, tnext);                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                \
+        const int nxt = (cb == 2) ? 0 : cb + 1;                                           \
+        na = &As[nxt][(g + 4 * kg) * SA + li];                                            \
+        nb = &Bs[nxt][(g + 4 * kg) * SB + 16 * wave + li];                                \
         _Pragma("unroll") for (int st = 0; st < NS; st++) {                               \
-            if (st + 2 < NS) G16_FR(st + 2, (st + 2) % 3);                                \
+            if (st + 2 < NS) G16_FR(p, st + 2, (st + 2) % 4);                             \
             _Pragma("unroll") for (int a = 0; a < RB; a++)                                \
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[st % 3], fa[st % 3][a], acc[a], 0, 0, 0); \
+                G16_MFMA(acc[a], fb[st % 4], fa[st % 4][a]);                              \
+            /* past the last tile the prefetch index is clamped (a redundant reload) and what is  \
+               staged is never read: a branch here would split the pinned instruction stream */   \
+            /* one global load and one LDS staging write per step (a burst of them stalls the wave   \
+               behind the CU's 64 B/clk vector-memory path and the MFMAs queue up behind it);         \
+               past the last tile the prefetch index is clamped (a redundant reload) and what is      \
+               staged is never read: a branch here would split the pinned instruction stream */       \
+            if (!G16X_NOLOAD) G16_LOADI(S2, st, min((tcur) + 2, kl));                     \
+            if (!G16X_NOSTAGE) G16_STAGEI(S1, st, nxt);                                   \
+            if (st == BAR && !G16X_NOBAR) __syncthreads();                                \
+            if (st == NS - 2) G16_FR(n, 0, 0);                                            \
+            if (st == NS - 1) G16_FR(n, 1, 1);                                            \
             __builtin_amdgcn_sched_barrier(0);                                            \
         }                                                                                 \
-        __syncthreads();                                                                  \
+        cb = nxt;                                                                         \
+        pa = na;                                                                          \
+        pb = nb;                                                                          \
     } while (0)
 
     if (KT > 0) {
+        constexpr int BAR = AV + BV;  // the step after the last staging write
+        static_assert(BAR <= NS - 3 && NS % 4 == 0, "step schedule");
+        // tiles 0 and 1 are requested together (one memory round trip instead of two)
         const int kl = KT - 1;
-        G16_LOAD(X, 0);
-        G16_STAGE(X, 0);
+        G16_LOAD(Y, 0);
         G16_LOAD(X, min(1, kl));
+        G16_STAGE_A(Y, 0);
+        G16_STAGE_B(Y, 0);
         __syncthreads();
-        float fa[3][RB], fb[3];
+        float fa[4][RB], fb[4];
+        int cb = 0;
+        const float* pa = &As[0][(g + 4 * kg) * SA + li];
+        const float* pb = &Bs[0][(g + 4 * kg) * SB + 16 * wave + li];
+        const float* na = pa;
+        const float* nb = pb;
+        G16_FR(n, 0, 0);
+        G16_FR(n, 1, 1);
+        GSTAMP(1);
         int t = 0;
         for (; t + 1 < KT; t += 2) {
-            G16_TILE(0, X, Y, min(t + 2, kl));
-            G16_TILE(1, Y, X, min(t + 3, kl));
+            G16_TILE(X, Y, t);
+            GSTAMP(2 + t);
+            G16_TILE(Y, X, t + 1);
+            GSTAMP(3 + t);
         }
-        if (t < KT) G16_TILE(0, X, Y, kl);
+        if (t < KT) G16_TILE(X, Y, t);
+#ifdef EKF_G16_ASM_MFMA
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+        GSTAMP(36);
+        __syncthreads();  // every wavefront is done with LDS (the reduction below reuses it)
     }
 #undef G16_TILE
 #undef G16_FR
 #undef G16_LOAD
-#undef G16_STAGE
+#undef G16_LOADI
+#undef G16_STAGEI
+#undef G16_STAGE_A
+#undef G16_STAGE_B
     if constexpr (WPS > 1) {
-        // sum the two k-interleaved partial accumulators through LDS (the staging buffers are free:
-        // every wavefront passed the barrier that ended the last K-tile)
+        // sum the two k-interleaved partial accumulators through LDS (the staging buffers are free)
         float* red = &As[0][0];
-        static_assert(2 * BKK * SA >= RB * 4 * 256, "reduction scratch");
+        static_assert(3 * BKK * SA >= RB * 4 * 256, "reduction scratch");
         if (kg == 1) {
 #pragma unroll
             for (int a = 0; a < RB; a++)
@@ -501,6 +588,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             for (int v = 0; v < 4; v++) acc[a][v] += red[(a * 4 + v) * 256 + tid];
     }
 
+    GSTAMP(37);
     // epilogue: lane -> row (contiguous in memory), register -> column
     float vout[RB][4];
 #pragma unroll
@@ -560,15 +648,23 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
         }
     }
+    float* cp = C + (size_t)jb * ldc + i0 + li;
+    if (i0 + BMt <= M && j0 + 64 <= N) {  // interior tile: no per-element tests
 #pragma unroll
-    for (int a = 0; a < RB; a++) {
-        const int i = i0 + 16 * a + li;
-        if (i < M) {
+        for (int a = 0; a < RB; a++)
 #pragma unroll
-            for (int v = 0; v < 4; v++)
-                if (jb + v < N) C[(size_t)(jb + v) * ldc + i] = vout[a][v];
+            for (int v = 0; v < 4; v++) cp[(size_t)v * ldc + 16 * a] = vout[a][v];
+    } else {
+#pragma unroll
+        for (int a = 0; a < RB; a++) {
+            if (i0 + 16 * a + li < M) {
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    if (jb + v < N) cp[(size_t)v * ldc + 16 * a] = vout[a][v];
+            }
         }
     }
+    GSTAMP(38);
 }
 
 // cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
