@@ -389,13 +389,19 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     // staging coordinates (scalars, not arrays: hipcc sends a loop-carried float4 array to scratch)
 #define G16_ACOORD(u)                                                                       \
     const int ea##u = min(tid + NT * u, AVT - 1);                                           \
-    const float* ag##u = A + (size_t)(kbeg + ea##u / (BMt / 4)) * lda + min(i0 + (ea##u % (BMt / 4)) * 4, Mread - 4); \
+    const int ao##u = ((ea##u / (BMt / 4)) * lda + min(i0 + (ea##u % (BMt / 4)) * 4, Mread - 4)) * 4; /* bytes */ \
     const int al##u = (ea##u / (BMt / 4)) * SA + (ea##u % (BMt / 4)) * 4;
     G16_ACOORD(0) G16_ACOORD(1) G16_ACOORD(2) G16_ACOORD(3)
 #undef G16_ACOORD
-    const float* bg = B + (size_t)(kbeg + (tid >> 4)) * ldb + j0 + (tid & 15) * 4;  // k-rows tid>>4, + BKS, ...
+    // operands are read through buffer descriptors: 32-bit per-lane offsets fixed for the whole K loop,
+    // one scalar offset per K-tile, and reads past column K return zero without touching memory
+    // (the prefetches issued beyond the last tile need no clamp)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, K * lda * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, K * ldb * 4, 0x00020000);
+    const int bo = ((tid >> 4) * ldb + j0 + (tid & 15) * 4) * 4;  // bytes; k-rows tid>>4, + BKS, ...
     const int bl = (tid >> 4) * SB + (tid & 15) * 4;
-    const size_t a_step = (size_t)BKK * lda, b_step = (size_t)BKK * ldb;
+    const int a_step = BKK * lda * 4, b_step = BKK * ldb * 4, b_rows = BKS * ldb * 4;  // bytes
+    const int a_base = kbeg * lda * 4, b_base = kbeg * ldb * 4;
     static_assert((BV == 4 || BV == 2) && AV >= 1 && AV <= 4, "staging is written for 1..4 float4 of A and 2 or 4 of B per thread");
 
     f32x4 acc[RB];
@@ -420,30 +426,28 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     Ya0 = Ya1 = Ya2 = Ya3 = Yb0 = Yb1 = Yb2 = Yb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define G16_LOAD(S, kt)                                                                                \
     do {                                                                                               \
-        const size_t ao_ = (size_t)(kt) * a_step;                                                      \
-        const float* bp_ = bg + (size_t)(kt) * b_step;                                                 \
-        S##a0 = *reinterpret_cast<const float4*>(ag0 + ao_);                                           \
-        if constexpr (AV > 1) S##a1 = *reinterpret_cast<const float4*>(ag1 + ao_);                     \
-        if constexpr (AV > 2) S##a2 = *reinterpret_cast<const float4*>(ag2 + ao_);                     \
-        if constexpr (AV > 3) S##a3 = *reinterpret_cast<const float4*>(ag3 + ao_);                     \
-        S##b0 = *reinterpret_cast<const float4*>(bp_);                                                 \
-        S##b1 = *reinterpret_cast<const float4*>(bp_ + (size_t)BKS * ldb);                             \
-        if constexpr (BV > 2) S##b2 = *reinterpret_cast<const float4*>(bp_ + (size_t)(2 * BKS) * ldb); \
-        if constexpr (BV > 2) S##b3 = *reinterpret_cast<const float4*>(bp_ + (size_t)(3 * BKS) * ldb); \
+        const int sa_ = a_base + (kt) * a_step, sb_ = b_base + (kt) * b_step;                          \
+        S##a0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao0, sa_, 0));                                                               \
+        if constexpr (AV > 1) S##a1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao1, sa_, 0));                                         \
+        if constexpr (AV > 2) S##a2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao2, sa_, 0));                                         \
+        if constexpr (AV > 3) S##a3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao3, sa_, 0));                                         \
+        S##b0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo, sb_, 0));                                                                \
+        S##b1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo + b_rows, sb_, 0));                                                       \
+        if constexpr (BV > 2) S##b2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo + 2 * b_rows, sb_, 0));                             \
+        if constexpr (BV > 2) S##b3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo + 3 * b_rows, sb_, 0));                             \
     } while (0)
 // item j of a K-tile's AV + BV float4 per thread: first the A pieces, then the B pieces
 #define G16_LOADI(S, j, kt)                                                                            \
     do {                                                                                               \
-        const size_t ao_ = (size_t)(kt) * a_step;                                                      \
-        const float* bp_ = bg + (size_t)(kt) * b_step;                                                 \
-        if ((j) == 0) S##a0 = *reinterpret_cast<const float4*>(ag0 + ao_);                             \
-        if ((j) == 1 && AV > 1) S##a1 = *reinterpret_cast<const float4*>(ag1 + ao_);                   \
-        if ((j) == 2 && AV > 2) S##a2 = *reinterpret_cast<const float4*>(ag2 + ao_);                   \
-        if ((j) == 3 && AV > 3) S##a3 = *reinterpret_cast<const float4*>(ag3 + ao_);                   \
-        if ((j) == AV) S##b0 = *reinterpret_cast<const float4*>(bp_);                                  \
-        if ((j) == AV + 1) S##b1 = *reinterpret_cast<const float4*>(bp_ + (size_t)BKS * ldb);          \
-        if ((j) == AV + 2 && BV > 2) S##b2 = *reinterpret_cast<const float4*>(bp_ + (size_t)(2 * BKS) * ldb); \
-        if ((j) == AV + 3 && BV > 2) S##b3 = *reinterpret_cast<const float4*>(bp_ + (size_t)(3 * BKS) * ldb); \
+        const int sa_ = a_base + (kt) * a_step, sb_ = b_base + (kt) * b_step;                          \
+        if ((j) == 0) S##a0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao0, sa_, 0));                                                 \
+        if ((j) == 1 && AV > 1) S##a1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao1, sa_, 0));                                       \
+        if ((j) == 2 && AV > 2) S##a2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao2, sa_, 0));                                       \
+        if ((j) == 3 && AV > 3) S##a3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ao3, sa_, 0));                                       \
+        if ((j) == AV) S##b0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo, sb_, 0));                                                 \
+        if ((j) == AV + 1) S##b1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo + b_rows, sb_, 0));                                    \
+        if ((j) == AV + 2 && BV > 2) S##b2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo + 2 * b_rows, sb_, 0));                      \
+        if ((j) == AV + 3 && BV > 2) S##b3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bo + 3 * b_rows, sb_, 0));                      \
     } while (0)
 #define G16_STAGEI(S, j, buf)                                                                          \
     do {                                                                                               \
@@ -516,9 +520,9 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
                staged is never read: a branch here would split the pinned instruction stream */   \
             /* one global load and one LDS staging write per step (a burst of them stalls the wave   \
                behind the CU's 64 B/clk vector-memory path and the MFMAs queue up behind it);         \
-               past the last tile the prefetch index is clamped (a redundant reload) and what is      \
+               past the last tile the loads fall outside the buffer (zeros, no traffic) and what is   \
                staged is never read: a branch here would split the pinned instruction stream */       \
-            if (!G16X_NOLOAD) G16_LOADI(S2, st, min((tcur) + 2, kl));                     \
+            if (!G16X_NOLOAD) G16_LOADI(S2, st, (tcur) + 2);                              \
             if (!G16X_NOSTAGE) G16_STAGEI(S1, st, nxt);                                   \
             if (st == BAR && !G16X_NOBAR) __syncthreads();                                \
             if (st == NS - 2) G16_FR(n, 0, 0);                                            \
@@ -534,9 +538,8 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
         constexpr int BAR = AV + BV;  // the step after the last staging write
         static_assert(BAR <= NS - 3 && NS % 4 == 0, "step schedule");
         // tiles 0 and 1 are requested together (one memory round trip instead of two)
-        const int kl = KT - 1;
         G16_LOAD(Y, 0);
-        G16_LOAD(X, min(1, kl));
+        G16_LOAD(X, 1);
         G16_STAGE_A(Y, 0);
         G16_STAGE_B(Y, 0);
         __syncthreads();
