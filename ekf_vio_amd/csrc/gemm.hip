@@ -418,6 +418,25 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             cpre[a][v] = (beta != 0.f && i < M && j < N) ? Cin[(size_t)j * ldcin + i] : 0.f;
         }
 
+    // EPI 1: the K R terms of G = K R - T[:, idx] depend only on the inputs: their two dependent memory
+    // round trips (inv_idx, then K and R) are paid here, under the K loop, not in the epilogue
+    int qv[4] = {-1, -1, -1, -1};
+    float kq[RB][4], kp[RB][4];
+    if (EPI == 1 && kg == 0) {  // the epilogue belongs to wavefronts 0-3
+        const int jbq = j0 + 16 * wave + 4 * g;
+#pragma unroll
+        for (int v = 0; v < 4; v++) qv[v] = epi.inv_idx[min(jbq + v, N - 1)];
+#pragma unroll
+        for (int a = 0; a < RB; a++) {
+            const int ic = min(i0 + 16 * a + li, M - 1);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int q = max(qv[v], 0);
+                kq[a][v] = A[(size_t)q * lda + ic] * epi.Rm[2 * q];
+                kp[a][v] = A[(size_t)(q ^ 1) * lda + ic] * epi.Rm[2 * q + 1];
+            }
+        }
+    }
     // Two staging register sets, X and Y, alternate between iterations (tile t+1 sits in one while
     // tile t+2 is loaded into the other).  With a single set hipcc loads into fresh registers and
     // copies them back at the loop edge, which parks a full memory round trip behind every K-tile.
@@ -606,20 +625,6 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     const int jb = j0 + 16 * wave + 4 * g;
     if (EPI == 1) {
         // G(i,q) = (K R)(i,q) - T(i, idx[q]) for the measured columns of this tile (A is K)
-        int qv[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) qv[v] = epi.inv_idx[min(jb + v, N - 1)];
-        float kq[RB][4], kp[RB][4];
-#pragma unroll
-        for (int a = 0; a < RB; a++) {
-            const int ic = min(i0 + 16 * a + li, M - 1);
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int q = max(qv[v], 0);
-                kq[a][v] = A[(size_t)q * lda + ic] * epi.Rm[2 * q];
-                kp[a][v] = A[(size_t)(q ^ 1) * lda + ic] * epi.Rm[2 * q + 1];
-            }
-        }
 #pragma unroll
         for (int a = 0; a < RB; a++) {
             const int i = i0 + 16 * a + li;
