@@ -91,12 +91,13 @@ def selftest_dist(args):
         dist.destroy_process_group()
 
 
-def cpu_baseline(n_landmarks, dt, budget_steps):
-    """The oracle (line-faithful fp32 restatement of the reference filter) timed on ONE host
-    core: the reference is single-threaded (no threads/OpenMP in its CMakeLists)."""
+def cpu_baseline(n_landmarks, dt, budget_steps, threads=1):
+    """The oracle (line-faithful fp32 restatement of the reference filter) timed on the host: on ONE
+    core (the reference is single-threaded: no threads/OpenMP in its CMakeLists) and, as a second
+    figure, with the oracle's OpenMP products on all cores of this box's share."""
     from oracle import OracleFilter, set_threads
     from ekf_vio_amd.sim import Scenario
-    set_threads(1)
+    set_threads(threads)
     sc = Scenario(n_landmarks, seed=0)
     f = OracleFilter(np.float32)
     f.add_new_features(sc.initial_features())
@@ -107,9 +108,11 @@ def cpu_baseline(n_landmarks, dt, budget_steps):
     for z, R, p in fr[2:]:
         f.process(dt), f.update(z, R, p)
     el = time.perf_counter() - t0
-    return {"value": budget_steps / el, "unit": "steps/s", "cores": 1, "kind": "port",
+    set_threads(1)
+    return {"value": budget_steps / el, "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": "%d steps of process+update at N=%d after a 2-step warm-up, fp32 oracle "
-                      "(oracle/ekf_oracle.hpp), 1 thread; %.1f s" % (budget_steps, n_landmarks, el)}
+                      "(oracle/ekf_oracle.hpp), %d thread%s; %.1f s" % (budget_steps, n_landmarks, threads,
+                                                                        "" if threads == 1 else "s (OpenMP)", el)}
 
 
 def main():
@@ -199,6 +202,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps or max(3, int(round(60.0 * (256.0 / N) ** 3)))
             extra["cpu_baseline"] = cpu_baseline(N, dt, steps)
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if ncpu > 1:
+                extra["cpu_baseline_all_cores"] = cpu_baseline(N, dt, max(3, steps // 2), threads=min(ncpu, 64))
         print(json.dumps(result_line(args, world, N, elapsed, extra)))
     g.close()
     if world > 1:
