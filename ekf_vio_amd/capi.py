@@ -35,7 +35,7 @@ SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_r
            "ekfvio_step_image", "ekfvio_imu",
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
            "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
-           "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps", "ekfvio_test_sweep_stamps",
+           "ekfvio_profile_update_gemms", "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps", "ekfvio_test_sweep_stamps",
            "ekfvio_test_cholesky_solve"]
 
 _lib = None
@@ -75,6 +75,7 @@ def load(build_if_missing=True):
         "ekfvio_synchronize": [vp], "ekfvio_profile_enable": [vp, i32], "ekfvio_profile_reset": [vp],
         "ekfvio_profile_count": [], "ekfvio_profile_name": [i32],
         "ekfvio_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
+        "ekfvio_profile_update_gemms": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "ekfvio_test_gemm": [vp, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, i32],
         "ekfvio_test_cholesky_solve": [vp, i32, i32, fp, fp, fp, fp, ip],
         "ekfvio_test_potrf_stamps": [vp, C.POINTER(C.c_int64)],

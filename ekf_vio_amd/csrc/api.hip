@@ -466,6 +466,41 @@ int ekfvio_profile_enable(ekfvio_filter* f, int32_t on) {
     }
     return EKFVIO_OK;
 }
+// Mean launch duration of the two P-update GEMMs at the shape of the most recent update, measured the way the
+// timed region runs them: `reps` pairs captured into one hipGraph (back-to-back launches on the handle's stream),
+// replayed once between two HIP events.  Outputs go to scratch; the filter state is unchanged.
+int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_launch_us, double* flops_per_launch) {
+    if (!f || reps <= 0 || !avg_launch_us) return EKFVIO_EINVAL;
+    if (f->last_m <= 0 || f->N <= 0) return EKFVIO_ESTATE;
+    HIPC(f, hipSetDevice(f->device));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPC(f, hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
+    launch_update_gemms_scratch(f, f->last_m, reps);
+    hipError_t ce = hipStreamEndCapture(f->stream, &g);
+    if (ce != hipSuccess || !g) {
+        f->last_error = std::string("graph capture: ") + hipGetErrorString(ce);
+        return EKFVIO_EDEVICE;
+    }
+    HIPC(f, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    HIPC(f, hipGraphLaunch(ge, f->stream));  // warm-up
+    HIPC(f, hipEventRecord(f->ev0, f->stream));
+    HIPC(f, hipGraphLaunch(ge, f->stream));
+    HIPC(f, hipEventRecord(f->ev1, f->stream));
+    HIPC(f, hipEventSynchronize(f->ev1));
+    float ms = 0;
+    HIPC(f, hipEventElapsedTime(&ms, f->ev0, f->ev1));
+    (void)hipGraphExecDestroy(ge);
+    // P2 is the predict's scratch and must stay zero outside the live block
+    HIPC(f, hipMemsetAsync(f->P2, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    *avg_launch_us = 1e3 * ms / (2.0 * reps);
+    const int m_pad = round_up(f->last_m, 64);
+    if (flops_per_launch) *flops_per_launch = 2.0 * f->n * (double)f->n * m_pad;
+    return EKFVIO_OK;
+}
 int ekfvio_profile_reset(ekfvio_filter* f) {
     if (!f) return EKFVIO_EINVAL;
     for (int i = 0; i < PC_COUNT; i++) f->prof[i] = ProfSlot();

@@ -92,6 +92,7 @@ struct ekfvio_filter {
     int* sweep_sync = nullptr; // [2*m_cap/64 + 4] ready/done counters + abort flag of the persistent sweep
     int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
     int num_cus = 0;
+    int last_m = 0;            // measurement rows of the most recent update (shape of its GEMMs)
     long long* sweep_dbg = nullptr;  // [512] s_memtime stamps of the persistent sweep (diagnostic; null = off)
     float* Km = nullptr;       // [ldp*m_cap]  Sigma H^T, solved in place into the Kalman gain
     float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
@@ -175,6 +176,9 @@ void launch_predict(ekfvio_filter* f, float dt);
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass,
                    int* d_frame_counter = nullptr, int frames = 0);
 void launch_check_sigma(ekfvio_filter* f, float* d_out);
+// The two P-update GEMM launches of an update with m measurement rows, `reps` times, into scratch (P2, Gm): the
+// filter state is not touched.  For timing the kernel under its production shape (ekfvio_profile_update_gemms).
+void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);
 // Augmented blocked Cholesky sweep (chol.hip): Saug = [A; X; I] (row blocks of 64; A is
 // m_pad x m_pad, X has n_pad rows) -> Laug = [L; X L^-T; L^-T], both ld x m_pad column-major.
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld);

@@ -704,6 +704,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     const int n_pad = round_up(n, EKF_TILE);
     const int lda = f->ld_aug;
+    f->last_m = m;
     {
         ProfScope ps(f, PC_GATHER);
         hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, N, m_pad, d_z, d_R, d_pass,
@@ -744,6 +745,22 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         ProfScope ps(f, PC_UPDATE_MISC);
         hipLaunchKernelGGL(mean_update_kernel, dim3((n + 63) / 64), dim3(256), 0, f->stream, f->Km, ld, n, 0, f->yres, f->mu,
                            d_frame_counter, frames);
+    }
+}
+
+void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
+    const int n = f->n, ld = f->ldp;
+    const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
+    GemmEpi e1, e2;
+    e1.mode = 1;
+    e1.inv_idx = f->inv_idx;
+    e1.Rm = f->Rm;
+    e1.G = f->Gm;
+    e1.ldg = ld;
+    e2.mode = 2;  // n = 0: no mean update, no frame counter
+    for (int r = 0; r < reps; r++) {
+        launch_gemm(f->stream, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P2, ld, 0, 0, &e1);
+        launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P2, ld, f->P2, ld, 1, 0, &e2);
     }
 }
 

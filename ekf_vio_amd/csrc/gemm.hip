@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
             if (q >= 0 && j < N && i < M) epi.G[(size_t)q * epi.ldg + i] = kr - vout[r];
         }
     }
-    if (EPI == 2 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (EPI == 2 && blockIdx.x == 0 && blockIdx.y == 0 && epi.n > 0) {
         // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256 * GROUPS) {
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             }
         }
     }
-    if (EPI == 2 && i0 == 0 && j0 == 0) {
+    if (EPI == 2 && i0 == 0 && j0 == 0 && epi.n > 0) {
         // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256) {

@@ -181,6 +181,13 @@ class TightlyCoupledEKF:
             out[self.lib.ekfvio_profile_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value)
         return out
 
+    def profile_update_gemms(self, reps=50):
+        """(mean launch duration in us, flops per launch) of the two P-update GEMMs at the shape of the
+        most recent update, replayed back to back from a hipGraph between two HIP events."""
+        us, fl = C.c_double(0), C.c_double(0)
+        self._chk(self.lib.ekfvio_profile_update_gemms(self.h, int(reps), C.byref(us), C.byref(fl)))
+        return us.value, fl.value
+
     # ---- raw kernels -------------------------------------------------------------------
     def test_gemm(self, A, B, C0, alpha=1.0, beta=0.0, transB=True, variant=0):
         """C = beta*C0 + alpha * A @ (B.T if transB else B); arrays are numpy [row, col]."""

@@ -397,3 +397,26 @@ def test_graph_replay_matches_per_call_bits():
         assert np.array_equal(sa[key], sb[key]), key
     a.close()
     b.close()
+
+
+def test_profile_update_gemms_leaves_state_untouched():
+    """The live GEMM timing harness of bench.py runs the two P-update GEMMs into scratch: the
+    filter state and the next steps are bit-identical with and without it."""
+    N, frames = 40, 6
+    sc = Scenario(N, seed=3)
+    fr = list(sc.frames(frames))
+    runs = []
+    for use in (False, True):
+        g = TightlyCoupledEKF(max_features=N)
+        g.addNewFeatures(sc.initial_features())
+        for i, (z, R, p) in enumerate(fr):
+            g.process(sc.dt)
+            g.updateWithFeaturePositions(z, R, p)
+            if use and i == 2:
+                us, fl = g.profile_update_gemms(5)
+                n, m_pad = 22 + 3 * N, 128
+                assert us > 0 and fl == 2.0 * n * n * m_pad
+        runs.append(g.get_state())
+        g.close()
+    for key in ("base_mu", "feat_mu", "Sigma"):
+        assert np.array_equal(runs[0][key], runs[1][key]), key
