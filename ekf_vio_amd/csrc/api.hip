@@ -68,6 +68,21 @@ static const char* kProfNames[PC_COUNT] = {"linearize",   "predict_structured", 
                                            "cholesky",    "solve",              "gemm_update",  "update_misc",
                                            "klt_pyramid", "klt_track"};
 
+// addNewFeatures (:58-94) with the `count` new (u,v) pairs already in f->zmeas on the device
+int add_features_device(ekfvio_filter* f, int count) {
+    if (count <= 0) return EKFVIO_OK;
+    if (f->N + count > f->cfg.max_features) return EKFVIO_ECAPACITY;
+    const float depth = f->cfg.default_point_depth;
+    const float inv_depth = (float)(1.0 / (double)depth);  // Feature.cpp:18  mu(2) = 1.0/depth
+    hipLaunchKernelGGL(add_features_kernel, dim3(64), dim3(256), 0, f->stream, f->P, f->ldp, f->n, count,
+                       f->cfg.default_point_homogenous_variance, f->cfg.default_point_depth_variance, f->mu,
+                       f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth);
+    HIPC(f, hipStreamSynchronize(f->stream));
+    f->N += count;
+    f->n += 3 * count;
+    return EKFVIO_OK;
+}
+
 extern "C" {
 
 int ekfvio_default_config(ekfvio_config* c) {
@@ -86,6 +101,11 @@ int ekfvio_default_config(ekfvio_config* c) {
     c->max_image_width = 640;
     c->max_image_height = 480;
     c->use_principal_point = 0;
+    c->inverse_image_scale = 1;   // D_INVERSE_IMAGE_SCALE is 4; 1 = the caller hands over frames already at working size
+    c->fast_threshold = 50;       // D_FAST_THRESHOLD
+    c->min_new_feature_dist = 30; // D_MIN_NEW_FEATURE_DIST
+    c->fast_blur_sigma = 0.f;     // D_FAST_BLUR_SIGMA (0 = no blur; other values are not implemented)
+    c->replenish = 0;             // 1: ekfvio_step_image runs replenishFeatures (EKFVIO.cpp:154,172) itself
     return EKFVIO_OK;
 }
 
@@ -147,6 +167,8 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     HIPC(f, hipEventCreate(&f->ev1));
     int rc = klt_alloc(f);
     if (rc != EKFVIO_OK) return rc;
+    rc = fast_alloc(f);
+    if (rc != EKFVIO_OK) return rc;
     return ekfvio_reset(f);
 }
 
@@ -161,6 +183,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
         if (p) hipFree(p);
     if (f->h_info) hipHostFree(f->h_info);
     klt_free(f);
+    fast_free(f);
     drop_graph(f);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
@@ -196,15 +219,7 @@ int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count) {
     HIPC(f, hipSetDevice(f->device));
     // stage uv through the (free between updates) zmeas buffer in chunks of max_features
     HIPC(f, hipMemcpyAsync(f->zmeas, uv, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
-    const float depth = f->cfg.default_point_depth;
-    const float inv_depth = (float)(1.0 / (double)depth);  // Feature.cpp:18  mu(2) = 1.0/depth
-    hipLaunchKernelGGL(add_features_kernel, dim3(64), dim3(256), 0, f->stream, f->P, f->ldp, f->n, count,
-                       f->cfg.default_point_homogenous_variance, f->cfg.default_point_depth_variance, f->mu,
-                       f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth);
-    HIPC(f, hipStreamSynchronize(f->stream));
-    f->N += count;
-    f->n += 3 * count;
-    return EKFVIO_OK;
+    return add_features_device(f, count);
 }
 
 int ekfvio_process(ekfvio_filter* f, float dt) {

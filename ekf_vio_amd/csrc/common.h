@@ -116,6 +116,17 @@ struct ekfvio_filter {
     float* klt_next_px = nullptr;  // [2*max_features]
     uint8_t* klt_status = nullptr; // [max_features]
     uint8_t* staging = nullptr;    // device staging for the uploaded image
+    // --- frame ingest + replenishment (fast.hip) ---
+    uint8_t* resized = nullptr;    // Frame::Frame's cv::resize output (max image size)
+    short* fast_score = nullptr;   // FAST score map of level 0 (-1 = no corner)
+    int* fast_kp_xy = nullptr;     // keypoints in raster order
+    short* fast_kp_score = nullptr;
+    int fast_kp_cap = 0;
+    uint8_t* occ_mask = nullptr;   // replenishFeatures' checkImg as a bit mask (global fallback for large frames)
+    int* fast_row_cnt = nullptr;   // [max_image_height] keypoints per row / exclusive row offsets
+    int* fast_row_off = nullptr;
+    int* new_xy = nullptr;         // pixels of the landmarks added by the last replenishment
+    int* fast_counts = nullptr;    // [0] keypoints found, [1] landmarks added
     double t_stamp = 0;
     bool have_stamp = false;
 
@@ -176,6 +187,16 @@ void launch_predict(ekfvio_filter* f, float dt);
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass,
                    int* d_frame_counter = nullptr, int frames = 0);
 void launch_check_sigma(ekfvio_filter* f, float* d_out);
+// klt.hip helpers shared with fast.hip
+int klt_level_pitch(int w);
+int klt_border();
+void klt_intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy);
+// fast.hip
+int fast_alloc(ekfvio_filter* f);
+void fast_free(ekfvio_filter* f);
+void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale);
+// api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
+int add_features_device(ekfvio_filter* f, int k);
 // The two P-update GEMM launches of an update with m measurement rows, `reps` times, into scratch (P2, Gm): the
 // filter state is not touched.  For timing the kernel under its production shape (ekfvio_profile_update_gemms).
 void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);

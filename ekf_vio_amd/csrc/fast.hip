@@ -1,0 +1,452 @@
+// ekf_vio_amd/csrc/fast.hip — frame ingest and landmark replenishment on the device.
+//
+// Reference:
+//   Frame::Frame (include/ekf_vio/Frame.cpp:15-42): cv::resize(img, Size(cols/s, rows/s)), K / s
+//   EKFVIO::replenishFeatures (include/ekf_vio/EKFVIO.cpp:224-311): cv::FAST(img, kp, FAST_THRESHOLD, true),
+//     occupancy image of filled circles (radius MIN_NEW_FEATURE_DIST) around the landmarks' pixels, first fit
+//     over the keypoints in detector (raster) order, kill-box test, addNewFeatures(pixel2Metric(...)).
+// The arithmetic is OpenCV 3.x's (resize.cpp 8-bit INTER_LINEAR, fast.cpp / fast_score.cpp TYPE_9_16,
+// drawing.cpp Circle): everything is integer, so the kernels are bit-exact against oracle/fast_oracle.cpp.
+//
+// Mapping: resize and the FAST segment test + score are one thread per pixel (the 16 ring pixels become two
+// 16-bit masks, "9 contiguous" is four shift-ands on the doubled mask).  Non-maximum suppression and the
+// raster-order compaction are three small launches (keypoints per row, scan over the rows, ordered write with
+// ballot prefixes inside a row), which keeps cv::FAST's keypoint order without a sort.  The first-fit selection is inherently sequential in
+// keypoint order: one wavefront takes 64 keypoints at a time, tests them against the occupancy mask in
+// parallel, accepts the first free one, stamps its circle (one lane per circle row, bit mask in LDS) and
+// re-tests the rest.
+#include "common.h"
+
+#define HIPF(f, expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            (f)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);   \
+            return EKFVIO_EDEVICE;                                                 \
+        }                                                                          \
+    } while (0)
+
+namespace {
+
+__device__ inline short sat_short_rn(float v) {
+    const int i = __float2int_rn(v);  // round half to even = cvRound
+    return (short)min(32767, max(-32768, i));
+}
+
+// cv::resize 8u INTER_LINEAR (resize.cpp): one thread per destination pixel
+__global__ void frame_resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int sstride, uint8_t* __restrict__ dst,
+                                    int dw, int dh, double scale_x, double scale_y) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    const int a0 = sat_short_rn((1.f - fx) * 2048), a1 = sat_short_rn(fx * 2048);
+    const int b0 = sat_short_rn((1.f - fy) * 2048), b1 = sat_short_rn(fy * 2048);
+    const int sx1 = min(sx + 1, sw - 1);
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+    const uint8_t *S0 = src + (size_t)sy0 * sstride, *S1 = src + (size_t)sy1 * sstride;
+    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
+    dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// FAST-9/16 segment test + cornerScore<16>; score map: -1 = no corner.  img points at pixel (0,0) of a pitched image.
+__global__ void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h, int pitch, int threshold, short* __restrict__ score) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    short out = -1;
+    if (x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
+        const uint8_t* p = img + (size_t)y * pitch + x;
+        const int v = p[0];
+        // ring in cv::FAST's order (fast.cpp makeOffsets, patternSize 16)
+        int q[16];
+        q[0] = p[3 * pitch];      q[1] = p[3 * pitch + 1];   q[2] = p[2 * pitch + 2];   q[3] = p[pitch + 3];
+        q[4] = p[3];              q[5] = p[-pitch + 3];      q[6] = p[-2 * pitch + 2];  q[7] = p[-3 * pitch + 1];
+        q[8] = p[-3 * pitch];     q[9] = p[-3 * pitch - 1];  q[10] = p[-2 * pitch - 2]; q[11] = p[-pitch - 3];
+        q[12] = p[-3];            q[13] = p[pitch - 3];      q[14] = p[2 * pitch - 2];  q[15] = p[3 * pitch - 1];
+        unsigned br = 0, dk = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            br |= (q[k] > v + threshold ? 1u : 0u) << k;
+            dk |= (q[k] < v - threshold ? 1u : 0u) << k;
+        }
+        auto run9 = [](unsigned m16) {
+            const unsigned m = m16 | (m16 << 16);
+            unsigned t = m & (m >> 1);   // runs >= 2
+            t &= t >> 2;                 // >= 4
+            t &= t >> 4;                 // >= 8
+            return (t & (m >> 8)) != 0;  // >= 9
+        };
+        if (run9(br) || run9(dk)) {
+            int d[25];
+#pragma unroll
+            for (int k = 0; k < 25; k++) d[k] = v - q[k & 15];
+            int a0 = threshold;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                int a = min(d[k + 1], d[k + 2]);
+                a = min(a, d[k + 3]);
+                a = min(a, d[k + 4]);
+                a = min(a, d[k + 5]);
+                a = min(a, d[k + 6]);
+                a = min(a, d[k + 7]);
+                a = min(a, d[k + 8]);
+                a0 = max(a0, min(a, d[k]));
+                a0 = max(a0, min(a, d[k + 9]));
+            }
+            int b0 = -a0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                int b = max(d[k + 1], d[k + 2]);
+                b = max(b, d[k + 3]);
+                b = max(b, d[k + 4]);
+                b = max(b, d[k + 5]);
+                b = max(b, d[k + 6]);
+                b = max(b, d[k + 7]);
+                b = max(b, d[k + 8]);
+                b0 = min(b0, max(b, d[k]));
+                b0 = min(b0, max(b, d[k + 9]));
+            }
+            out = (short)(-b0 - 1);
+        }
+    }
+    score[(size_t)y * w + x] = out;
+}
+
+// non-maximum suppression: strict > against the 8 neighbours of the score map (fast.cpp)
+__device__ inline bool fast_keep(const short* __restrict__ score, int w, int h, int x, int y, int nonmax) {
+    if (x < 3 || x >= w - 3) return false;
+    const short s = score[(size_t)y * w + x];
+    if (s < 0) return false;
+    if (!nonmax) return true;
+    const short* r0 = score + (size_t)(y - 1) * w + x;
+    const short* r1 = score + (size_t)y * w + x;
+    const short* r2 = score + (size_t)(y + 1) * w + x;
+    return s > r0[-1] && s > r0[0] && s > r0[1] && s > r1[-1] && s > r1[1] && s > r2[-1] && s > r2[0] && s > r2[1];
+}
+
+// raster-order compaction in three small launches: keypoints per row, exclusive scan over the rows, ordered write
+__global__ __launch_bounds__(256) void fast_row_count_kernel(const short* __restrict__ score, int w, int h, int nonmax, int* row_cnt) {
+    __shared__ int s_part[4];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    int c = 0;
+    if (y >= 3 && y < h - 3)
+        for (int x = tid; x < w; x += 256) c += fast_keep(score, w, h, x, y, nonmax) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) row_cnt[y] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+__global__ __launch_bounds__(1024) void fast_row_scan_kernel(const int* __restrict__ row_cnt, int h, int* row_off, int* total) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int y0 = 0; y0 < h; y0 += 1024) {
+        const int y = y0 + tid;
+        const int c = (y < h) ? row_cnt[y] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            before += (q < wv) ? s_w[q] : 0;
+            tot += s_w[q];
+        }
+        const int carry = s_carry;
+        if (y < h) row_off[y] = carry + before + incl - c;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void fast_row_write_kernel(const short* __restrict__ score, int w, int h, int nonmax, int cap,
+                                                             const int* __restrict__ row_off, int* __restrict__ kp_xy,
+                                                             short* __restrict__ kp_score) {
+    __shared__ int s_w[4];
+    __shared__ int s_base;
+    const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (y < 3 || y >= h - 3) return;
+    if (tid == 0) s_base = row_off[y];
+    __syncthreads();
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + tid;
+        const bool keep = x < w && fast_keep(score, w, h, x, y, nonmax);
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_w[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            before += (q < wv) ? s_w[q] : 0;
+            tot += s_w[q];
+        }
+        const int base = s_base;
+        if (keep) {
+            const int o = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap) {
+                kp_xy[2 * o] = x;
+                kp_xy[2 * o + 1] = y;
+                kp_score[o] = score[(size_t)y * w + x];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base = base + tot;
+        __syncthreads();
+    }
+}
+
+// drawing.cpp Circle(), filled: half-width of the span in row cy + dyrow (-1: the row is outside the circle)
+__device__ inline int circle_half_width(int radius, int dyrow) {
+    // The midpoint walk emits, for each step (dx, dy): rows +-dy get half-width dx, rows +-dx get half-width dy.
+    // A row |r| is reached as a "dy row" while dx >= dy, and as a "dx row" each time dx takes the value |r|
+    // (then with the LAST dy written before dx decrements being the widest).  Re-walk it: the circle is small.
+    const int ar = dyrow < 0 ? -dyrow : dyrow;
+    int best = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dy == ar) best = max(best, dx);
+        if (dx == ar) best = max(best, dy);
+        dy++;
+        err += plus;
+        plus += 2;
+        const int m = (err <= 0) - 1;
+        err -= minus & m;
+        dx += m;
+        minus -= m & 2;
+    }
+    return best;
+}
+
+// The occupancy image (checkImg) as a bit mask: in LDS when it fits (w*h bits <= 64 KB: every 640x480-class
+// frame), otherwise in global memory behind agent-scope atomics (one wavefront reads what it just wrote).
+#define OCC_LDS_WORDS 16384
+template <bool LDSMASK>
+struct OccMask {
+    unsigned* words;  // LDS or global, (w + 31) / 32 words per row
+    int wpr;
+    __device__ inline bool test(int x, int y) const {
+        const unsigned* p = words + (size_t)y * wpr + (x >> 5);
+        const unsigned v = LDSMASK ? *p : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (v >> (x & 31)) & 1u;
+    }
+    __device__ inline void set_span(int y, int xa, int xb) const {  // bits xa..xb of row y
+        for (int wd = xa >> 5; wd <= (xb >> 5); wd++) {
+            const int lo = max(xa, wd * 32) - wd * 32, hi = min(xb, wd * 32 + 31) - wd * 32;
+            const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            unsigned* p = words + (size_t)y * wpr + wd;
+            if (LDSMASK) atomicOr(p, m);
+            else __hip_atomic_fetch_or(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+// one lane per row of the circle: lane l of pass q owns row offset -radius + 64 q + l; its half-width is fixed for
+// the whole kernel (hw[q], -1 = no such row), so stamping a circle is one to three word ORs per lane
+#define OCC_PASSES 2  // radii up to 63
+template <bool LDSMASK>
+__device__ inline void stamp_circle(const OccMask<LDSMASK>& mask, int w, int h, int cx, int cy, int radius, int lane,
+                                    const int (&hw)[OCC_PASSES]) {
+#pragma unroll
+    for (int q = 0; q < OCC_PASSES; q++) {
+        const int y = cy - radius + 64 * q + lane;
+        if (hw[q] < 0 || y < 0 || y >= h) continue;
+        const int xa = max(cx - hw[q], 0), xb = min(cx + hw[q], w - 1);
+        if (xa <= xb) mask.set_span(y, xa, xb);
+    }
+}
+
+// replenishFeatures' selection: one wavefront.  The global mask (LDSMASK = false) is zeroed by the caller.
+template <bool LDSMASK>
+__global__ __launch_bounds__(64) void replenish_select_kernel(const int* __restrict__ kp_xy, const int* __restrict__ kp_count, int cap_kp,
+                                                              const float* __restrict__ mu, int N_old, float fx, float fy, float cx,
+                                                              float cy, int num_features, int w, int h, int radius, int kill_pad,
+                                                              unsigned* gmask, int* new_xy, float* new_uv, int* new_count) {
+    __shared__ unsigned lmask[LDSMASK ? OCC_LDS_WORDS : 1];
+    const int lane = threadIdx.x;
+    OccMask<LDSMASK> mask;
+    mask.wpr = (w + 31) / 32;
+    mask.words = LDSMASK ? lmask : gmask;
+    if (LDSMASK) {
+        for (int i = lane; i < mask.wpr * h; i += 64) lmask[i] = 0u;
+        __syncthreads();
+    }
+    int hw[OCC_PASSES];
+#pragma unroll
+    for (int q = 0; q < OCC_PASSES; q++) {
+        const int rr = -radius + 64 * q + lane;
+        hw[q] = (rr <= radius) ? circle_half_width(radius, rr) : -1;
+    }
+    // occupancy of the existing landmarks: circle at cv::Point(getPixel(f)) = cvRound of (u*fx + cx, v*fy + cy)
+    for (int i = 0; i < N_old; i++) {
+        const float u = mu[EKF_BASE + 3 * i], v = mu[EKF_BASE + 3 * i + 1];
+        const int px = __float2int_rn(u * fx + cx), py = __float2int_rn(v * fy + cy);
+        stamp_circle(mask, w, h, px, py, radius, lane, hw);
+    }
+    __syncthreads();  // one wavefront: orders the mask writes before the reads below (lgkmcnt / vmcnt drained)
+    int wanted = num_features - N_old, added = 0;
+    const int nk = min(*kp_count, cap_kp);
+    for (int c0 = 0; c0 < nk && added < wanted; c0 += 64) {
+        const int k = c0 + lane;
+        int x = 0, y = 0;
+        bool cand = false;
+        if (k < nk) {
+            x = kp_xy[2 * k];
+            y = kp_xy[2 * k + 1];
+            cand = !(x < kill_pad || y < kill_pad || w - x < kill_pad || h - y < kill_pad);  // Frame::isPixelInBox
+        }
+        unsigned long long todo = __ballot(cand);
+        while (todo && added < wanted) {
+            // test the remaining candidates against the current mask
+            const bool is_free = cand && ((todo >> lane) & 1ull) && !mask.test(x, y);
+            const unsigned long long fb = __ballot(is_free);
+            if (!fb) break;
+            const int L = __ffsll((long long)fb) - 1;
+            const int ax = __shfl(x, L, 64), ay = __shfl(y, L, 64);
+            if (lane == 0) {
+                new_xy[2 * added] = ax;
+                new_xy[2 * added + 1] = ay;
+                // Feature::pixel2Metric (Feature.h:60-62)
+                new_uv[2 * added] = ((float)ax - cx) / fx;
+                new_uv[2 * added + 1] = ((float)ay - cy) / fy;
+            }
+            added++;
+            stamp_circle(mask, w, h, ax, ay, radius, lane, hw);
+            __syncthreads();
+            todo &= ~((2ull << L) - 1ull);  // everything up to and including L is consumed
+        }
+    }
+    if (lane == 0) *new_count = added;
+}
+
+}  // namespace
+
+int fast_alloc(ekfvio_filter* f) {
+    const ekfvio_config& c = f->cfg;
+    const size_t px = (size_t)c.max_image_width * c.max_image_height;
+    HIPF(f, hipMalloc((void**)&f->resized, px));
+    HIPF(f, hipMalloc((void**)&f->fast_score, px * sizeof(short)));
+    f->fast_kp_cap = (int)(px / 4 + 1);
+    HIPF(f, hipMalloc((void**)&f->fast_kp_xy, (size_t)f->fast_kp_cap * 2 * sizeof(int)));
+    HIPF(f, hipMalloc((void**)&f->fast_kp_score, (size_t)f->fast_kp_cap * sizeof(short)));
+    HIPF(f, hipMalloc((void**)&f->occ_mask, ((size_t)(c.max_image_width + 31) / 32) * c.max_image_height * sizeof(unsigned)));
+    HIPF(f, hipMalloc((void**)&f->fast_row_cnt, (size_t)c.max_image_height * sizeof(int)));
+    HIPF(f, hipMalloc((void**)&f->fast_row_off, (size_t)c.max_image_height * sizeof(int)));
+    const int maxf = c.max_features > 0 ? c.max_features : 1;
+    HIPF(f, hipMalloc((void**)&f->new_xy, (size_t)maxf * 2 * sizeof(int)));
+    HIPF(f, hipMalloc((void**)&f->fast_counts, 4 * sizeof(int)));
+    return EKFVIO_OK;
+}
+
+void fast_free(ekfvio_filter* f) {
+    void* ptrs[] = {f->resized, f->fast_score, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt, f->fast_row_off};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+// Frame::Frame's cv::resize: f->staging (w x h, tightly packed) -> f->resized ((w/s) x (h/s))
+void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale) {
+    const int dw = w / inv_scale, dh = h / inv_scale;
+    hipLaunchKernelGGL(frame_resize_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, f->stream, f->staging, w, h, w, f->resized, dw,
+                       dh, (double)w / dw, (double)h / dh);
+}
+
+// cv::FAST on level 0 of the current frame -> f->fast_kp_* (raster order), count in f->fast_counts[0]
+int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax) {
+    const KltFrame& fr = f->frames[f->cur];
+    if (!fr.valid) {
+        f->last_error = "FAST needs a frame";
+        return EKFVIO_ESTATE;
+    }
+    const int w = fr.w[0], h = fr.h[0], pitch = klt_level_pitch(w);
+    const uint8_t* img0 = fr.img[0] + (size_t)klt_border() * pitch + klt_border();
+    hipLaunchKernelGGL(fast_score_kernel, dim3((w + 255) / 256, h), dim3(256), 0, f->stream, img0, w, h, pitch, threshold, f->fast_score);
+    hipLaunchKernelGGL(fast_row_count_kernel, dim3(h), dim3(256), 0, f->stream, f->fast_score, w, h, nonmax, f->fast_row_cnt);
+    hipLaunchKernelGGL(fast_row_scan_kernel, dim3(1), dim3(1024), 0, f->stream, f->fast_row_cnt, h, f->fast_row_off, f->fast_counts);
+    hipLaunchKernelGGL(fast_row_write_kernel, dim3(h), dim3(256), 0, f->stream, f->fast_score, w, h, nonmax, f->fast_kp_cap, f->fast_row_off,
+                       f->fast_kp_xy, f->fast_kp_score);
+    return EKFVIO_OK;
+}
+
+extern "C" {
+
+int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score, int32_t* count) {
+    if (!f || !count || cap < 0) return EKFVIO_EINVAL;
+    HIPF(f, hipSetDevice(f->device));
+    int rc = fast_detect_device(f, threshold, nonmax);
+    if (rc != EKFVIO_OK) return rc;
+    int n = 0;
+    HIPF(f, hipMemcpyAsync(&n, f->fast_counts, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPF(f, hipStreamSynchronize(f->stream));
+    *count = n;
+    const int k = std::min(std::min(n, cap), f->fast_kp_cap);
+    if (k > 0 && xy) HIPF(f, hipMemcpyAsync(xy, f->fast_kp_xy, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, f->stream));
+    if (k > 0 && score) {
+        std::vector<short> hs(k);
+        HIPF(f, hipMemcpyAsync(hs.data(), f->fast_kp_score, sizeof(short) * k, hipMemcpyDeviceToHost, f->stream));
+        HIPF(f, hipStreamSynchronize(f->stream));
+        for (int i = 0; i < k; i++) score[i] = hs[i];
+    }
+    HIPF(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+// EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame
+int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy) {
+    if (!f) return EKFVIO_EINVAL;
+    if (f->cfg.fast_blur_sigma != 0.f) {
+        f->last_error = "FAST_BLUR_SIGMA != 0 (cv::GaussianBlur before FAST) is not implemented";
+        return EKFVIO_EINVAL;
+    }
+    if (f->cfg.min_new_feature_dist < 0 || f->cfg.min_new_feature_dist > 64 * OCC_PASSES / 2 - 1) {
+        f->last_error = "min_new_feature_dist must be in [0, 63]";
+        return EKFVIO_EINVAL;
+    }
+    HIPF(f, hipSetDevice(f->device));
+    if (added) *added = 0;
+    if (f->N >= f->cfg.max_features) return EKFVIO_OK;  // "if (tc_ekf.features.size() < NUM_FEATURES)" (:236)
+    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1);
+    if (rc != EKFVIO_OK) return rc;
+    const KltFrame& fr = f->frames[f->cur];
+    const int w = fr.w[0], h = fr.h[0];
+    float fx, fy, cx, cy;
+    klt_intrinsics(f, fr.K, &fx, &fy, &cx, &cy);
+    const size_t mask_words = (size_t)((w + 31) / 32) * h;
+    if (mask_words <= OCC_LDS_WORDS) {
+        hipLaunchKernelGGL(replenish_select_kernel<true>, dim3(1), dim3(64), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
+                           f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
+                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
+    } else {
+        HIPF(f, hipMemsetAsync(f->occ_mask, 0, mask_words * sizeof(unsigned), f->stream));
+        hipLaunchKernelGGL(replenish_select_kernel<false>, dim3(1), dim3(64), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
+                           f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
+                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
+    }
+    int k = 0;
+    HIPF(f, hipMemcpyAsync(&k, f->fast_counts + 1, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPF(f, hipStreamSynchronize(f->stream));
+    if (k > 0 && new_px_xy) HIPF(f, hipMemcpyAsync(new_px_xy, f->new_xy, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, f->stream));
+    if (k > 0) {
+        rc = add_features_device(f, k);  // uv already in f->zmeas
+        if (rc != EKFVIO_OK) return rc;
+    }
+    HIPF(f, hipStreamSynchronize(f->stream));
+    if (added) *added = k;
+    return EKFVIO_OK;
+}
+
+}  // extern "C"

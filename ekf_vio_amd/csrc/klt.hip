@@ -315,6 +315,10 @@ PyrView make_view(const KltFrame& fr) {
 
 }  // namespace
 
+int klt_level_pitch(int w) { return level_pitch(w); }
+int klt_border() { return KLT_BORDER; }
+void klt_intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy);
+
 int klt_alloc(ekfvio_filter* f) {
     const ekfvio_config& c = f->cfg;
     if (c.klt_window_size < 3 || c.klt_window_size > KLT_MAX_WIN || (c.klt_window_size & 1) == 0 ||
@@ -355,7 +359,7 @@ void klt_free(ekfvio_filter* f) {
 }
 
 // Device-side part of klt_push_frame: staging -> pyramid + derivatives of frames[cur]
-static int build_pyramid(ekfvio_filter* f, KltFrame& fr, int w, int h) {
+static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int w, int h) {
     const int win = f->cfg.klt_window_size;
     fr.w[0] = w;
     fr.h[0] = h;
@@ -370,7 +374,7 @@ static int build_pyramid(ekfvio_filter* f, KltFrame& fr, int w, int h) {
     ProfScope ps(f, PC_KLT_PYRAMID);
     {
         const int pw = w + 2 * KLT_BORDER, ph = h + 2 * KLT_BORDER;
-        hipLaunchKernelGGL(klt_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, f->stream, f->staging, w, h, w,
+        hipLaunchKernelGGL(klt_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, f->stream, src, w, h, w,
                            fr.img[0], level_pitch(w));
     }
     for (int l = 1; l < fr.levels; l++) {
@@ -385,6 +389,10 @@ static int build_pyramid(ekfvio_filter* f, KltFrame& fr, int w, int h) {
     return EKFVIO_OK;
 }
 
+static void intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy);
+void klt_intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy) {
+    intrinsics(f, K, fx, fy, cx, cy);
+}
 static void intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy) {
     // CameraInfo.K is row-major [fx 0 cx; 0 fy cy; 0 0 1].  Feature.h:60-66 reads K(0), K(4)
     // and, for the offsets, K(2) and K(5) of a column-major Matrix3f = the zero entries K[2,0]
@@ -436,12 +444,23 @@ int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width,
                           const float K[9]) {
     if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
     if (width > f->cfg.max_image_width || height > f->cfg.max_image_height) return EKFVIO_ECAPACITY;
+    // Frame::Frame (Frame.cpp:15-42): cv::resize to (cols / s, rows / s), K(0,0), K(0,2), K(1,1), K(1,2) divided by s
+    const int s = f->cfg.inverse_image_scale > 1 ? f->cfg.inverse_image_scale : 1;
+    const int w = width / s, h = height / s;
+    if (w < 1 || h < 1) return EKFVIO_EINVAL;
     HIPK(f, hipSetDevice(f->device));
     HIPK(f, hipMemcpy2DAsync(f->staging, width, image, stride, width, height, hipMemcpyHostToDevice, f->stream));
     f->cur ^= 1;  // the former current frame becomes the previous one (frame_buffer depth 2)
     KltFrame& fr = f->frames[f->cur];
     for (int i = 0; i < 9; i++) fr.K[i] = K[i];
-    build_pyramid(f, fr, width, height);
+    if (s > 1) {
+        fr.K[0] = (float)((double)K[0] / s);
+        fr.K[2] = (float)((double)K[2] / s);
+        fr.K[4] = (float)((double)K[4] / s);
+        fr.K[5] = (float)((double)K[5] / s);
+        launch_frame_resize(f, width, height, s);
+    }
+    build_pyramid(f, fr, s > 1 ? f->resized : f->staging, w, h);
     fr.valid = true;
     HIPK(f, hipGetLastError());
     HIPK(f, hipStreamSynchronize(f->stream));  // the caller's image buffer may be reused
@@ -503,8 +522,9 @@ int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h
     return EKFVIO_OK;
 }
 
-// EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) minus ROS publishing and
-// FAST replenishment (the caller adds landmarks with ekfvio_add_features).
+// EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) minus ROS publishing; with
+// cfg.replenish the FAST replenishment of :154 / :172 runs on the device too (otherwise the caller
+// adds landmarks with ekfvio_add_features).
 int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                       const float K[9]) {
     if (!f) return EKFVIO_EINVAL;
@@ -518,6 +538,7 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
             f->t_stamp = stamp;
             f->have_stamp = true;
         }
+        if (f->cfg.replenish) return ekfvio_replenish(f, nullptr, nullptr);  // replenishFeatures(first frame) (:154)
         return EKFVIO_OK;
     }
     const float dt = (float)(stamp - f->t_stamp);
@@ -542,6 +563,10 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         }
     }
     HIPK(f, hipGetLastError());
+    if (f->cfg.replenish) {  // "try to get more features if needed" (:172)
+        rc = ekfvio_replenish(f, nullptr, nullptr);
+        if (rc != EKFVIO_OK) return rc;
+    }
     return status;
 }
 

@@ -259,6 +259,10 @@ class KLTTracker:
         return img, der
 
 
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
 class EKFVIO:
     """Host mirror of the step sequence of EKFVIO::addFrame / updateStateWithNewImage
     (include/ekf_vio/EKFVIO.cpp:139-219) without ROS: frames in, odometry + landmark cloud out.
@@ -274,6 +278,25 @@ class EKFVIO:
         K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
         return self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_step_image(self.tc_ekf.h, float(stamp), _u8(img), w, h, w, _fp(K)),
                                 allow=(capi.ENUMERIC,))
+
+    def replenishFeatures(self):
+        """EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame, on the device: FAST-9/16 with
+        non-maximum suppression, occupancy circles, first fit, addNewFeatures.  Returns the new landmarks' pixels."""
+        k = C.c_int32(0)
+        px = np.zeros((max(self.tc_ekf.cfg.max_features, 1), 2), np.int32)
+        self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_replenish(self.tc_ekf.h, C.byref(k), _ip(px)))
+        return px[:k.value].copy()
+
+    def fast(self, threshold=50, nonmax=True):
+        """cv::FAST on the current (resized) frame: (xy[n,2], score[n]) in raster order."""
+        w, h = C.c_int32(0), C.c_int32(0)
+        self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_klt_get_level(self.tc_ekf.h, 0, C.byref(w), C.byref(h), None, None))
+        cap = w.value * h.value
+        xy, sc, n = np.zeros((cap, 2), np.int32), np.zeros(cap, np.int32), C.c_int32(0)
+        self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_fast_detect(self.tc_ekf.h, int(threshold), int(bool(nonmax)), cap, _ip(xy), _ip(sc),
+                                                            C.byref(n)))
+        k = min(n.value, cap)
+        return xy[:k].copy(), sc[:k].copy()
 
     def imu_callback(self, stamp, gyro, accel):
         """EKFVIO::imu_callback (EKFVIO.cpp:113-115): a logging stub in the reference."""

@@ -48,6 +48,7 @@ class TightlyCoupledEKF {
         if (cfg) c = *cfg;
         else ekfvio_default_config(&c);
         if (!cfg) c.max_features = max_features;
+        max_features_ = c.max_features;
         int rc = ekfvio_create(&c, device, nullptr, &h_);
         if (rc != EKFVIO_OK) {
             std::string msg = h_ ? ekfvio_last_error(h_) : "ekfvio_create failed";
@@ -121,6 +122,7 @@ class TightlyCoupledEKF {
         return out;
     }
     int numFeatures() const { return ekfvio_num_features(h_); }
+    int maxFeatures() const { return max_features_; }
     int dim() const { return ekfvio_dim(h_); }
     ekfvio_filter* handle() { return h_; }
 
@@ -130,6 +132,7 @@ class TightlyCoupledEKF {
 
    private:
     ekfvio_filter* h_ = nullptr;
+    int max_features_ = 0;
 };
 
 class KLTTracker {
@@ -156,9 +159,21 @@ class KLTTracker {
 // The step sequence of EKFVIO::addFrame (EKFVIO.cpp:139-196) with the ROS plumbing removed.
 class EKFVIO {
    public:
-    explicit EKFVIO(int max_features = 100, int device = 0) : tc_ekf(max_features, device), tracker(tc_ekf) {}
+    explicit EKFVIO(int max_features = 100, int device = 0, const ekfvio_config* cfg = nullptr)
+        : tc_ekf(max_features, device, cfg), tracker(tc_ekf) {}
     TightlyCoupledEKF tc_ekf;
     KLTTracker tracker;
+
+    // EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the frame pushed last: FAST-9/16 + occupancy first fit +
+    // addNewFeatures, all on the device.  Returns the number of landmarks added.  With cfg.replenish = 1
+    // addFrame() does this itself at the two places the reference does (:154, :172).
+    int replenishFeatures(std::vector<int32_t>* new_pixels_xy = nullptr) {
+        int32_t added = 0;
+        if (new_pixels_xy) new_pixels_xy->assign(2 * (size_t)tc_ekf.maxFeatures(), 0);
+        tc_ekf.chk(ekfvio_replenish(tc_ekf.handle(), &added, new_pixels_xy ? new_pixels_xy->data() : nullptr));
+        if (new_pixels_xy) new_pixels_xy->resize(2 * (size_t)added);
+        return added;
+    }
 
     // returns false on a numeric warning (see updateWithFeaturePositions)
     bool addFrame(const Frame& f) {

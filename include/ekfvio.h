@@ -62,6 +62,12 @@ typedef struct ekfvio_config {
     int32_t max_image_width;               /* device pyramid capacity */
     int32_t max_image_height;
     int32_t use_principal_point;           /* 0 reproduces Feature.h:60-66 (cx,cy ignored) */
+    /* frame ingest and landmark replenishment (Frame.cpp:15-42, EKFVIO.cpp:224-311, Params.h:24-28,43) */
+    int32_t inverse_image_scale;           /* INVERSE_IMAGE_SCALE: frames are resized to (w/s, h/s), K/s; reference default 4, here 1 */
+    int32_t fast_threshold;                /* FAST_THRESHOLD 50 */
+    int32_t min_new_feature_dist;          /* MIN_NEW_FEATURE_DIST 30 (radius of the occupancy circles) */
+    float fast_blur_sigma;                 /* FAST_BLUR_SIGMA 0 = off; non-zero is rejected (not implemented) */
+    int32_t replenish;                     /* 1: ekfvio_step_image also runs replenishFeatures */
 } ekfvio_config;
 
 /* Fills `cfg` with the reference defaults (Params.h D_* values). */
@@ -138,6 +144,16 @@ int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h
  * (FAST) stays with the caller: add landmarks with ekfvio_add_features afterwards. */
 int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height,
                       int32_t stride, const float K[9]);
+
+/* EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame: cv::FAST(threshold, nonmax) on the
+ * (resized) image, occupancy circles of radius min_new_feature_dist around the landmarks' pixels, first fit
+ * in detector order with the kill-box test, addNewFeatures(pixel2Metric(.)) until max_features landmarks
+ * exist.  `added` (may be NULL) receives the number of new landmarks, new_px_xy (may be NULL, room for
+ * 2*max_features ints) their pixels. */
+int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy);
+/* Test hook: cv::FAST(level 0 of the current frame, threshold, nonmax), TYPE_9_16, keypoints in raster order. */
+int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score,
+                       int32_t* count);
 /* EKFVIO::imu_callback (EKFVIO.cpp:113-115) is a logging stub in the reference; kept so the
  * node shim has somewhere to deliver IMU records.  No arithmetic. */
 int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float accel[3]);

@@ -18,7 +18,7 @@ BASE = 22
 
 def build_oracle(force=False):
     """Compile the oracle with g++ (make -C oracle)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.hpp", "ekf_oracle_capi.cpp", "klt_oracle.cpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.hpp", "ekf_oracle_capi.cpp", "klt_oracle.cpp", "fast_oracle.cpp", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -70,6 +70,10 @@ def _declare(lib):
     lib.orc_klt_track.argtypes = [vp, vp, fpp, fpp, i32, i32, i32, C.c_float, C.c_float, i32, u8p, ip]
     lib.orc_set_threads.argtypes = [i32]
     lib.orc_max_threads.restype = i32
+    lib.orc_frame_resize.argtypes = [u8p, i32, i32, i32, i32, u8p]
+    lib.orc_fast_detect.argtypes = [u8p, i32, i32, i32, i32, i32, i32, ip, ip]
+    lib.orc_circle_fill.argtypes = [u8p, i32, i32, i32, i32, i32]
+    lib.orc_replenish.argtypes = [u8p, i32, i32, i32, fpp, i32, i32, i32, i32, i32, i32, ip]
 
 
 def set_threads(t):
@@ -241,3 +245,46 @@ def klt_track(prev, nxt, prev_px, init_px, win=21, max_iter=30, epsilon=0.01, mi
     lib.orc_klt_track(prev.p, nxt.p, _p(pp, C.c_float), _p(nn, C.c_float), n, win, max_iter, epsilon, min_eig,
                       accum_mode, _p(st, C.c_uint8), it.ctypes.data_as(C.POINTER(C.c_int)))
     return nn, st, it
+
+
+# ---- frame ingest and landmark replenishment (fast_oracle.cpp) ----
+def frame_resize(img, inv_scale):
+    """Frame::Frame image part: cv::resize(img, Size(cols / s, rows / s)), INTER_LINEAR, 8-bit."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((h // inv_scale, w // inv_scale), np.uint8)
+    rc = oracle_lib().orc_frame_resize(_p(img, C.c_uint8), w, h, w, int(inv_scale), _p(out, C.c_uint8))
+    assert rc == 0
+    return out
+
+
+def fast_detect(img, threshold=50, nonmax=True):
+    """cv::FAST(img, kp, threshold, nonmax), TYPE_9_16: (xy[n,2] int32 in raster order, score[n] int32)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = (w * h) // 4 + 1 if nonmax else w * h
+    xy = np.zeros((cap, 2), np.int32)
+    sc = np.zeros(cap, np.int32)
+    n = oracle_lib().orc_fast_detect(_p(img, C.c_uint8), w, h, w, int(threshold), int(bool(nonmax)), cap,
+                                     xy.ctypes.data_as(C.POINTER(C.c_int)), sc.ctypes.data_as(C.POINTER(C.c_int)))
+    return xy[:n].copy(), sc[:n].copy()
+
+
+def circle_fill(mask, cx, cy, radius):
+    """cv::circle(mask, (cx, cy), radius, 255, -1) in place."""
+    assert mask.dtype == np.uint8 and mask.flags["C_CONTIGUOUS"]
+    h, w = mask.shape
+    oracle_lib().orc_circle_fill(_p(mask, C.c_uint8), w, h, int(cx), int(cy), int(radius))
+    return mask
+
+
+def replenish(img, existing_px, num_features, threshold=50, min_dist=30, kill_pad=11):
+    """EKFVIO::replenishFeatures on a scaled frame: pixels (int32 [k,2]) of the landmarks to add."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    ex = np.ascontiguousarray(existing_px, dtype=np.float32).reshape(-1, 2)
+    cap = max(int(num_features), 1)
+    out = np.zeros((cap, 2), np.int32)
+    n = oracle_lib().orc_replenish(_p(img, C.c_uint8), w, h, w, _p(ex, C.c_float), ex.shape[0], int(num_features),
+                                   int(threshold), int(min_dist), int(kill_pad), cap, out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out[:n].copy()

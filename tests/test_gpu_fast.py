@@ -1,0 +1,127 @@
+"""Frame ingest (Frame::Frame resize) and landmark replenishment (EKFVIO::replenishFeatures) on the device against
+oracle/fast_oracle.cpp: all integer work, so everything is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from ekf_vio_amd import EKFVIO, KLTTracker, TightlyCoupledEKF, capi
+from oracle import fast_detect, frame_resize, replenish
+
+pytestmark = pytest.mark.gpu
+IMG = os.path.join(os.path.dirname(__file__), "golden", "images")
+K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)
+
+
+def grey(name):
+    return np.asarray(Image.open(os.path.join(IMG, name + "_gray.png")))
+
+
+@pytest.mark.parametrize("scale,crop", [(2, None), (4, None), (3, None), (2, (251, 333)), (4, (479, 637)), (5, (120, 160))])
+def test_frame_resize_bit_exact(scale, crop):
+    img = grey("640_480_test")
+    if crop:
+        img = np.ascontiguousarray(img[:crop[0], :crop[1]])
+    ekf = TightlyCoupledEKF(max_features=4, inverse_image_scale=scale)
+    trk = KLTTracker(ekf)
+    trk.push_frame(img, K)
+    got, _ = trk.level(0)
+    ref = frame_resize(img, scale)
+    assert got.shape == ref.shape == (img.shape[0] // scale, img.shape[1] // scale)
+    assert np.array_equal(got, ref)
+    ekf.close()
+
+
+@pytest.mark.parametrize("name,thr,nonmax", [("640_480_test", 50, True), ("640_480_test", 20, True), ("640_480_test", 50, False),
+                                             ("640_480_moved_test", 50, True), ("640_480_shear_test", 35, True)])
+def test_fast_keypoints_and_scores_bit_exact(name, thr, nonmax):
+    path = os.path.join(IMG, name + "_gray.png")
+    if not os.path.exists(path):
+        pytest.skip("image not in tests/golden/images")
+    img = grey(name)
+    v = EKFVIO(max_features=4)
+    v.tracker.push_frame(img, K)
+    xy, sc = v.fast(thr, nonmax)
+    rxy, rsc = fast_detect(img, thr, nonmax)
+    assert len(rxy) > 20
+    assert np.array_equal(xy, rxy) and np.array_equal(sc, rsc)
+    v.tc_ekf.close()
+
+
+def test_fast_on_resized_frame_and_small_images():
+    img = grey("640_480_test")
+    v = EKFVIO(max_features=4, inverse_image_scale=2)
+    v.tracker.push_frame(img, K)
+    xy, sc = v.fast(30, True)
+    rxy, rsc = fast_detect(frame_resize(img, 2), 30, True)
+    assert len(rxy) > 5 and np.array_equal(xy, rxy) and np.array_equal(sc, rsc)
+    v.tc_ekf.close()
+    # ragged width (not a multiple of the compaction chunk) and a tiny image (nothing but border)
+    w = EKFVIO(max_features=4)
+    w.tracker.push_frame(np.ascontiguousarray(img[:77, :203]), K)
+    xy, sc = w.fast(20, True)
+    rxy, rsc = fast_detect(np.ascontiguousarray(img[:77, :203]), 20, True)
+    assert np.array_equal(xy, rxy) and np.array_equal(sc, rsc)
+    w.tracker.push_frame(np.ascontiguousarray(img[:6, :6]), K)
+    xy, sc = w.fast(20, True)
+    assert len(xy) == 0
+    w.tc_ekf.close()
+
+
+def test_replenish_matches_oracle_and_feeds_the_filter():
+    img = grey("640_480_test")
+    v = EKFVIO(max_features=100)
+    assert v.addFrame(1.0, img, K) == capi.OK
+    assert v.tc_ekf.num_features == 0
+    px = v.replenishFeatures()
+    ref = replenish(img, np.zeros((0, 2), np.float32), 100)
+    assert len(ref) > 10 and np.array_equal(px, ref)
+    st = v.tc_ekf.get_state()
+    assert v.tc_ekf.num_features == len(ref)
+    uv = np.stack([px[:, 0].astype(np.float32) / K[0], px[:, 1].astype(np.float32) / K[4]], axis=1)  # pixel2Metric, cx = cy = 0 quirk
+    assert np.array_equal(st["feat_mu"][:, :2], uv) and np.array_equal(st["last_klt"], uv)
+    assert np.all(st["feat_mu"][:, 2] == np.float32(2.0)) and st["del_flag"].sum() == 0
+    # a second call on the same frame: every keypoint left is within 30 px of a landmark or out of the box
+    more = v.replenishFeatures()
+    ref2 = replenish(img, px.astype(np.float32), 100)
+    assert np.array_equal(more, ref2)
+    v.tc_ekf.close()
+
+
+def test_replenish_respects_existing_landmarks():
+    img = grey("640_480_test")
+    v = EKFVIO(max_features=60)
+    v.addFrame(1.0, img, K)
+    seeds = np.array([[100.3, 80.2], [320.0, 240.5], [500.7, 400.1], [-20.0, 10.0]], np.float32)  # one outside the image
+    uv = np.stack([seeds[:, 0] / K[0], seeds[:, 1] / K[4]], axis=1).astype(np.float32)
+    v.tc_ekf.addNewFeatures(uv)
+    # getPixel (Feature.cpp:34-36) = u * fx (+0), v * fy (+0) in fp32
+    ex = np.stack([uv[:, 0] * K[0], uv[:, 1] * K[4]], axis=1).astype(np.float32)
+    px = v.replenishFeatures()
+    ref = replenish(img, ex, 60)
+    assert np.array_equal(px, ref) and v.tc_ekf.num_features == 4 + len(ref) <= 60
+    v.tc_ekf.close()
+
+
+def test_step_image_with_replenish_runs_the_whole_addframe_sequence():
+    """EKFVIO::addFrame (EKFVIO.cpp:139-196) entirely behind the C-ABI: frame 1 = ingest + FAST replenishment,
+    frame 2 = process, KLT, update, replenishment."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    v = EKFVIO(max_features=64, replenish=1)
+    assert v.addFrame(10.0, a, K) == capi.OK
+    n1 = v.tc_ekf.num_features
+    ref = replenish(a, np.zeros((0, 2), np.float32), 64)
+    assert n1 == len(ref) > 10
+    rc = v.addFrame(10.0 + 1.0 / 30.0, b, K)
+    assert rc in (capi.OK, capi.ENUMERIC)
+    st = v.tc_ekf.get_state()
+    assert n1 <= v.tc_ekf.num_features <= 64
+    assert np.isfinite(st["base_mu"]).all() and np.isfinite(st["Sigma"]).all()
+    assert abs(np.linalg.norm(st["base_mu"][3:7]) - 1) < 1e-6
+    # the image moved by (-21, -7) px: tracked landmarks report it
+    moved = (st["last_klt"][:n1] - st["feat_mu"][:n1, :2] * 0)  # measured metric positions of the first batch
+    good = st["del_flag"][:n1] == 0
+    d = moved[good] * np.array([K[0], K[4]], np.float32) - ref[good].astype(np.float32)
+    assert good.sum() >= n1 // 2 and np.all(np.abs(np.median(d, axis=0) - np.array([-21.0, -7.0])) < 0.05)
+    v.tc_ekf.close()
