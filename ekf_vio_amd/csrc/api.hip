@@ -422,8 +422,10 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
             HIPC(f, hipStreamSynchronize(f->stream));
             HIPC(f, hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
             for (int k = 0; k < EKF_GRAPH_STEPS; k++) {
-                launch_predict(f, dt);
-                launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames);
+                // the frame's measurement bookkeeping rides in the linearisation launch
+                const BookArgs bk = make_book_args(f, m, f->seq_z, f->seq_R, f->seq_pass, counter);
+                launch_predict(f, dt, &bk);
+                launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames, true);
             }
             hipError_t ce = hipStreamEndCapture(f->stream, &g);
             if (ce != hipSuccess || !g) {

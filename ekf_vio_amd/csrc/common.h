@@ -79,7 +79,7 @@ struct ekfvio_filter {
     float* zmeas = nullptr;    // [2*max_features] device copy of z
     float* Rmeas = nullptr;    // [4*max_features]
     uint8_t* pass = nullptr;   // [max_features]
-    float* yres = nullptr;     // [m_cap] residual
+    float* yres = nullptr;     // [m_cap] measured coordinate per measurement row (the residual is formed in gather_kernel)
     float* Rm = nullptr;       // [m_cap*2] per measurement row r: R(r,r) and the off-diagonal partner
     // Augmented sweep matrices, ld_aug x m_cap, column-major.  Row blocks of Saug:
     //   [0, m_pad)                 A = (H Sigma H^T + R)^T           -> Laug: L (Cholesky factor)
@@ -181,11 +181,27 @@ void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, i
 
 void gemm_set_stamp_buffer(long long* d_buf);  // diagnostics: nullptr disables
 
-void launch_linearize(ekfvio_filter* f, float dt);
+// Measurement bookkeeping of one update (device pointers); see bookkeeping_body in ekf_kernels.hip
+struct BookArgs {
+    int enabled = 0;
+    int N = 0, m_pad = 0;
+    const float* z = nullptr;
+    const float* R = nullptr;
+    const uint8_t* pass = nullptr;
+    float* last_klt = nullptr;
+    uint8_t* del_flag = nullptr;
+    int* idx = nullptr;
+    int* inv_idx = nullptr;
+    float* zrow = nullptr;  // measured coordinate per measurement row (f->yres)
+    float* Rm = nullptr;
+    const int* frame_counter = nullptr;
+};
+BookArgs make_book_args(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, const int* d_frame_counter);
+void launch_linearize(ekfvio_filter* f, float dt, const BookArgs* book = nullptr);
 void launch_build_dense_F(ekfvio_filter* f, float* Fdense);
-void launch_predict(ekfvio_filter* f, float dt);
+void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book = nullptr);
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass,
-                   int* d_frame_counter = nullptr, int frames = 0);
+                   int* d_frame_counter = nullptr, int frames = 0, bool bookkeeping_done = false);
 void launch_check_sigma(ekfvio_filter* f, float* d_out);
 // klt.hip helpers shared with fast.hip
 int klt_level_pitch(int w);

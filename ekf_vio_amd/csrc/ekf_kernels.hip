@@ -134,9 +134,101 @@ __device__ inline float two_delta() { return (float)(2 * 1e-3); }
 // formed through LDS.  The last workgroup produces the 22x22 base block A (32 evaluations of
 // convolveBaseState on 32 lanes) and the propagated base mean.
 // ---------------------------------------------------------------------------------------
+// Body of the bookkeeping (formFeatureMeasurementMap :634-661 and the per-landmark loop of :492-530) for one
+// workgroup of NT threads.  zrow receives the measured coordinate of every measurement row (the residual
+// z - H mu is formed by gather_kernel, once the propagated mean exists), so this depends only on the frame's
+// measurements: it can run as an extra workgroup of the linearisation launch (BookArgs) or on its own.
+template <int NT>
+__device__ __forceinline__ void bookkeeping_body(const BookArgs& a) {
+    __shared__ int s_cnt[32];
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    const int N = a.N, m_pad = a.m_pad;
+    const float* z = a.z;
+    const float* R = a.R;
+    const uint8_t* pass = a.pass;
+    if (a.frame_counter) {
+        const int fi = *a.frame_counter;
+        z += (size_t)fi * 2 * N;
+        R += (size_t)fi * 4 * N;
+        pass += (size_t)fi * N;
+    }
+    const int per = (N + NT - 1) / NT;
+    const int lo = tid * per;
+    const int hi = min(N, lo + per);
+    int c = 0;
+    for (int i = lo; i < hi; i++) c += pass[i] ? 1 : 0;
+    // exclusive scan of the NT per-thread counts: shuffle scan inside each wavefront, then
+    // the wavefront totals are scanned by wavefront 0 (two barriers in all)
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / 64;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_cnt[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        int t = (lane < NW) ? s_cnt[lane] : 0;
+        int ti = t;
+#pragma unroll
+        for (int off = 1; off < NW; off <<= 1) {
+            const int v = __shfl_up(ti, off, 64);
+            if (lane >= off) ti += v;
+        }
+        if (lane < NW) s_cnt[16 + lane] = ti - t;  // exclusive prefix of the wavefront totals
+        if (lane == NW - 1) s_total = ti;
+    }
+    __syncthreads();
+    int base = s_cnt[16 + wv] + incl - c;
+    for (int i = lo; i < hi; i++) {
+        if (pass[i]) {
+            const int r = 2 * base;
+            const int s = EKF_BASE + 3 * i;
+            a.last_klt[2 * i] = z[2 * i];
+            a.last_klt[2 * i + 1] = z[2 * i + 1];
+            a.idx[r] = s;
+            a.idx[r + 1] = s + 1;
+            a.zrow[r] = z[2 * i];
+            a.zrow[r + 1] = z[2 * i + 1];
+            // Rm[2c] = R(c,c), Rm[2c+1] = R(c^1,c) (the off-diagonal element of column c);
+            // input is a column-major 2x2: [cov(0,0), cov(1,0), cov(0,1), cov(1,1)]
+            a.Rm[2 * r] = R[4 * i + 0];
+            a.Rm[2 * r + 1] = R[4 * i + 1];
+            a.Rm[2 * r + 2] = R[4 * i + 3];
+            a.Rm[2 * r + 3] = R[4 * i + 2];
+            a.inv_idx[s] = r;
+            a.inv_idx[s + 1] = r + 1;
+            a.inv_idx[s + 2] = -1;
+            base++;
+        } else {
+            a.del_flag[i] = 1;
+            a.inv_idx[EKF_BASE + 3 * i] = a.inv_idx[EKF_BASE + 3 * i + 1] = a.inv_idx[EKF_BASE + 3 * i + 2] = -1;
+        }
+    }
+    __syncthreads();
+    const int m = 2 * s_total;
+    for (int r = m + tid; r < m_pad; r += NT) {
+        a.idx[r] = -1;
+        a.zrow[r] = 0.f;
+        a.Rm[2 * r] = 0.f;
+        a.Rm[2 * r + 1] = 0.f;
+    }
+    if (tid <= EKF_BASE) a.inv_idx[tid == EKF_BASE ? EKF_BASE + 3 * N : tid] = -1;  // base state and the K*y column
+}
+
 #define LIN_LM 8
 __global__ __launch_bounds__(256) void linearize_kernel(const float* __restrict__ mu, int N, float dt, float* FA,
-                                                        float* FB, float* FD, float* mu_next) {
+                                                        float* FB, float* FD, float* mu_next, BookArgs book) {
+    // device-resident sequences: the measurement bookkeeping of the coming update rides along as one more
+    // workgroup (it does not depend on the propagated state)
+    if (book.enabled && blockIdx.x == gridDim.x - 1) {
+        bookkeeping_body<256>(book);
+        return;
+    }
+    const int base_block = (int)gridDim.x - 1 - (book.enabled ? 1 : 0);
     __shared__ float s_base[EKF_BASE];
     __shared__ BaseMotion s_bm[19];            // 0: unperturbed, 1+2c: col 7+c plus, 2+2c: minus
     __shared__ float s_hi[16][EKF_BASE];       // base workgroup: convolveBaseState at +delta
@@ -146,7 +238,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(const float* __restrict_
     if (tid < EKF_BASE) s_base[tid] = mu[tid];
     __syncthreads();
     const float td = two_delta();
-    if (blockIdx.x == gridDim.x - 1) {
+    if ((int)blockIdx.x == base_block) {
         if (tid < 32) {
             // 32 evaluations of convolveBaseState: column j = 0..15, high and low test points
             const int j = tid >> 1;
@@ -464,85 +556,7 @@ __global__ void add_noise_flush_kernel(float* P, int ld, int n, float dt) {
 // ---------------------------------------------------------------------------------------
 // With a frame counter (device-resident sequences replayed from a hipGraph) the measurement
 // of frame *frame_counter is used and the counter advances modulo `frames`.
-__global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_pad, const float* __restrict__ z,
-                                                                  const float* __restrict__ R,
-                                                                  const uint8_t* __restrict__ pass,
-                                                                  const float* __restrict__ mu, float* last_klt,
-                                                                  uint8_t* del_flag, int* idx, int* inv_idx, float* yres,
-                                                                  float* Rm, const int* frame_counter) {
-    __shared__ int s_cnt[32];
-    __shared__ int s_total;
-    const int tid = threadIdx.x;
-    if (frame_counter) {
-        const int fi = *frame_counter;
-        z += (size_t)fi * 2 * N;
-        R += (size_t)fi * 4 * N;
-        pass += (size_t)fi * N;
-    }
-    const int per = (N + 1023) / 1024;
-    const int lo = tid * per;
-    const int hi = min(N, lo + per);
-    int c = 0;
-    for (int i = lo; i < hi; i++) c += pass[i] ? 1 : 0;
-    // exclusive scan of the 1024 per-thread counts: shuffle scan inside each wavefront, then
-    // the 16 wavefront totals are scanned by wavefront 0 (two barriers in all)
-    const int lane = tid & 63, wv = tid >> 6;
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) s_cnt[wv] = incl;
-    __syncthreads();
-    if (wv == 0) {
-        int t = (lane < 16) ? s_cnt[lane] : 0;
-        int ti = t;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const int v = __shfl_up(ti, off, 64);
-            if (lane >= off) ti += v;
-        }
-        if (lane < 16) s_cnt[16 + lane] = ti - t;  // exclusive prefix of the wavefront totals
-        if (lane == 15) s_total = ti;
-    }
-    __syncthreads();
-    int base = s_cnt[16 + wv] + incl - c;
-    for (int i = lo; i < hi; i++) {
-        if (pass[i]) {
-            const int r = 2 * base;
-            const int s = EKF_BASE + 3 * i;
-            last_klt[2 * i] = z[2 * i];
-            last_klt[2 * i + 1] = z[2 * i + 1];
-            idx[r] = s;
-            idx[r + 1] = s + 1;
-            yres[r] = z[2 * i] - mu[s];
-            yres[r + 1] = z[2 * i + 1] - mu[s + 1];
-            // Rm[2c] = R(c,c), Rm[2c+1] = R(c^1,c) (the off-diagonal element of column c);
-            // input is a column-major 2x2: [cov(0,0), cov(1,0), cov(0,1), cov(1,1)]
-            Rm[2 * r] = R[4 * i + 0];
-            Rm[2 * r + 1] = R[4 * i + 1];
-            Rm[2 * r + 2] = R[4 * i + 3];
-            Rm[2 * r + 3] = R[4 * i + 2];
-            inv_idx[s] = r;
-            inv_idx[s + 1] = r + 1;
-            inv_idx[s + 2] = -1;
-            base++;
-        } else {
-            del_flag[i] = 1;
-            inv_idx[EKF_BASE + 3 * i] = inv_idx[EKF_BASE + 3 * i + 1] = inv_idx[EKF_BASE + 3 * i + 2] = -1;
-        }
-    }
-    __syncthreads();
-    const int m = 2 * s_total;
-    for (int r = m + tid; r < m_pad; r += 1024) {
-        idx[r] = -1;
-        yres[r] = 0.f;
-        Rm[2 * r] = 0.f;
-        Rm[2 * r + 1] = 0.f;
-    }
-    if (tid <= EKF_BASE) inv_idx[tid == EKF_BASE ? EKF_BASE + 3 * N : tid] = -1;  // base state and the K*y column
-}
+__global__ __launch_bounds__(1024) void update_bookkeeping_kernel(BookArgs a) { bookkeeping_body<1024>(a); }
 
 // A = (H Sigma H^T + R)^T (:559-561, :578), padded with the identity.  The reference hands
 // S.transpose() to SimplicialLDLT, which reads the LOWER triangle of what it is given, i.e.
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(int N, int m_p
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P, int ld, int n,
                                                      const int* __restrict__ idx, const float* __restrict__ Rm, int m,
                                                      int m_pad, int n_pad, float* Saug, int lda, float* Wt,
-                                                     const float* __restrict__ yres, float* G) {
+                                                     const float* __restrict__ zrow, const float* __restrict__ mu, float* G) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;  // measurement column
     const int sc = (c < m) ? idx[c] : 0;
@@ -584,7 +598,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P
             w = P[(size_t)i * ld + sc];   // Sigma(idx[c], i)
         }
         if (i < n_pad) Saug[(size_t)c * lda + m_pad + i] = cv;
-        if (i == n) w = (c < m) ? -yres[c] : 0.f;  // extra row: the Joseph-1 GEMM then yields K*y in column n
+        // extra row: -(z - H mu) (:554-555), so that the Joseph-1 GEMM yields K*y in column n
+        if (i == n) w = (c < m) ? -(zrow[c] - mu[sc]) : 0.f;
         Wt[(size_t)c * ld + i] = w;
         if (c >= m) G[(size_t)c * ld + i] = 0.f;   // padding columns of G stay zero
     }
@@ -656,11 +671,32 @@ __global__ void check_sigma_kernel(const float* P, int ld, int n, float* out) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
-void launch_linearize(ekfvio_filter* f, float dt) {
+void launch_linearize(ekfvio_filter* f, float dt, const BookArgs* book) {
     ProfScope ps(f, PC_LINEARIZE);
-    const int blocks = (f->N + LIN_LM - 1) / LIN_LM + 1;  // landmark workgroups + the base-block workgroup
+    BookArgs b;
+    if (book) b = *book;
+    // landmark workgroups + the base-block workgroup (+ the bookkeeping workgroup)
+    const int blocks = (f->N + LIN_LM - 1) / LIN_LM + 1 + (b.enabled ? 1 : 0);
     hipLaunchKernelGGL(linearize_kernel, dim3(blocks), dim3(256), 0, f->stream, f->mu, f->N, dt, f->FA, f->FB, f->FD,
-                       f->mu_next);
+                       f->mu_next, b);
+}
+
+BookArgs make_book_args(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, const int* d_frame_counter) {
+    BookArgs a;
+    a.enabled = 1;
+    a.N = f->N;
+    a.m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
+    a.z = d_z;
+    a.R = d_R;
+    a.pass = d_pass;
+    a.last_klt = f->last_klt;
+    a.del_flag = f->del_flag;
+    a.idx = f->idx;
+    a.inv_idx = f->inv_idx;
+    a.zrow = f->yres;
+    a.Rm = f->Rm;
+    a.frame_counter = d_frame_counter;
+    return a;
 }
 
 void launch_build_dense_F(ekfvio_filter* f, float* Fdense) {
@@ -670,8 +706,8 @@ void launch_build_dense_F(ekfvio_filter* f, float* Fdense) {
 }
 
 // process(dt) (:96-121)
-void launch_predict(ekfvio_filter* f, float dt) {
-    launch_linearize(f, dt);
+void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
+    launch_linearize(f, dt, book);
     const int n = f->n, ld = f->ldp;
     dim3 grid((n + 255) / 256, n);
     if (f->cfg.predict_mode == EKFVIO_PREDICT_DENSE) {
@@ -699,7 +735,7 @@ void launch_predict(ekfvio_filter* f, float dt) {
 
 // updateWithFeaturePositions (:475-628) on device-resident z/R/pass; m = 2*(#passed) known to the host
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, int* d_frame_counter,
-                   int frames) {
+                   int frames, bool bookkeeping_done) {
     const int n = f->n, ld = f->ldp, N = f->N;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     const int n_pad = round_up(n, EKF_TILE);
@@ -707,12 +743,13 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     f->last_m = m;
     {
         ProfScope ps(f, PC_GATHER);
-        hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, N, m_pad, d_z, d_R, d_pass,
-                           f->mu, f->last_klt, f->del_flag, f->idx, f->inv_idx, f->yres, f->Rm, d_frame_counter);
+        if (!bookkeeping_done)
+            hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream,
+                               make_book_args(f, m, d_z, d_R, d_pass, d_frame_counter));
         if (m > 0) {
             const int gx = (std::max(ld, m_pad) + 255) / 256;
             hipLaunchKernelGGL(gather_kernel, dim3(gx, m_pad), dim3(256), 0, f->stream, f->P, ld, n, f->idx, f->Rm, m,
-                               m_pad, n_pad, f->Saug, lda, f->Wt, f->yres, f->Gm);
+                               m_pad, n_pad, f->Saug, lda, f->Wt, f->yres, f->mu, f->Gm);
         }
     }
     GemmEpi e2;
