@@ -392,7 +392,14 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
 // row blocks (X: the forward substitution Y L^T = X rides along; I: yields L^-T).
 // idb0 = first identity row block: its block row q is still zero left of column block q.
 __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
-                                                        float* __restrict__ Linv, int k, int mb, int idb0, int* info) {
+                                                        float* __restrict__ Linv, int k, int mb, int idb0, int* info,
+                                                        long long* dbg) {
+    // diagnostic phase stamps of the chain workgroup (scripts/chol_step_stamps.py); dbg is null in production
+#define CSTAMP(slot)                                                                                         \
+    do {                                                                                                     \
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[32 + 8 * k + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    CSTAMP(0);
     __shared__ float Ti[PB * PLD];   // A_ik, then L_ik
     __shared__ float Tj[PB * PLD];   // A_jk, then L_jk
     __shared__ float Tl[PB * PLD];   // L_kk, later the updated next diagonal tile
@@ -419,11 +426,13 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
     if (i != j) load_tile(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
     __syncthreads();
+    CSTAMP(1);
     if (i != j)
         tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
     else
         tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
     __syncthreads();
+    CSTAMP(2);
     if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
     // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
     const float* Bj = (i != j) ? Tj : Ti;
@@ -438,10 +447,13 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
             Tl[c * PLD + r] = Sij[(size_t)c * lds + r] - up[q];
         }
         __syncthreads();
+        CSTAMP(3);
         const bool bad = potrf64_lds(Tl, Tinv, tid);
+        CSTAMP(4);
         store_tile_lower(Tl, L + (size_t)j * PB * ldl + (size_t)i * PB, ldl, tid);
         store_inv(Tinv, Linv + (size_t)(k + 1) * PB * PB, tid);
         if (bad && tid == 0) atomicOr(info, 1);
+        CSTAMP(5);
     } else {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -752,7 +764,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     for (int k = 0; k + 1 < mb; k++) {
         const int r = mb - 1 - k;
         hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2 + rb * r), dim3(256), 0, f->stream, Saug, ld, Laug, ld,
-                           Linv, k, mb, idb0, f->info);
+                           Linv, k, mb, idb0, f->info, f->sweep_dbg);
     }
     hipLaunchKernelGGL(chol_last_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb);
 }

@@ -1,0 +1,20 @@
+"""In-kernel phase stamps (s_memtime cycles) of the chain workgroup of chol_step_kernel during a filter update."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ekf_vio_amd import TightlyCoupledEKF
+from ekf_vio_amd.sim import Scenario
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+sc = Scenario(N, seed=0)
+g = TightlyCoupledEKF(max_features=N)
+g.addNewFeatures(sc.initial_features())
+g.lib.ekfvio_test_sweep_stamps(g.h, 1, None)
+for z, R, p in sc.frames(6):
+    g.process(sc.dt)
+    g.updateWithFeaturePositions(z, R, p)
+st = (C.c_int64 * 1024)()
+g.lib.ekfvio_test_sweep_stamps(g.h, 1, st)
+v = list(st)
+names = ["loads+sync", "panel solve", "rank-64 update", "factorisation", "stores"]
+for k in range((2 * N + 63) // 64 - 1):
+    b = 32 + 8 * k
+    print("step %2d: " % k + "  ".join("%s %6d" % (names[i], v[b + i + 1] - v[b + i]) for i in range(5)) + "   | in-kernel total %6d cycles = %.2f us at 2.4 GHz" % (v[b + 5] - v[b], (v[b + 5] - v[b]) / 2400.0))
