@@ -378,7 +378,7 @@ __device__ inline float process_noise(int i, float dt) {
 // add (X = F*P first, then X*F^T), i.e. the order of the reference's sparse products.
 // ---------------------------------------------------------------------------------------
 #define PT 16  // landmarks per tile side (landmark x landmark tiles)
-#define PC 21  // landmarks per chunk (63 state rows / columns) in the base-row / base-column workgroups
+#define PC 3   // landmarks per base-row / base-column workgroup (3*PC <= 64)
 
 __device__ __forceinline__ float predict_finish(float acc, int i, int j, float dt) {
     if (i == j) acc = acc + process_noise(i, dt);
