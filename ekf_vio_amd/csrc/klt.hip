@@ -102,19 +102,73 @@ __global__ void klt_scharr_kernel(const uint8_t* __restrict__ img, int w, int h,
     o[1] = (short)((t1p + t1m) * 3 + t1c * 10);
 }
 
-__device__ inline long long wave_sum(long long v) {
+// Exact sum over the wavefront of per-lane int32 partials (|v| < 2^28, so 8-lane sums fit in int32): a DPP
+// butterfly inside each group of 8 lanes (quad_perm xor 1, xor 2, row_half_mirror), then the eight group sums
+// are read out with v_readlane and added as 64-bit scalars.  No LDS round trips (a __shfl_xor butterfly on
+// 64-bit values is 12 dependent ds_bpermute).  The result is wave-uniform.
+__device__ inline long long wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane i <-> 7 - i
+    long long s = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int g8 = 0; g8 < 8; g8++) s += (long long)__builtin_amdgcn_readlane(v, 8 * g8);
+    return s;
 }
 __device__ inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
+// Copies `rows` rows of `nbytes` bytes starting at byte address src (row stride `pitch`, a multiple of 4) into LDS
+// with aligned 4-byte loads: LDS row r holds the aligned dwords that cover the span, LDP dwords per row.  Returns
+// the byte offset of the first wanted byte inside an LDS row (the same for every row).  MAXR x LDP bounds the
+// element count at compile time, so that all loads of a lane are issued before the first LDS write.
+template <int MAXR, int LDP>
+struct RowStage {
+    static constexpr int NL = (MAXR * LDP + 63) / 64;  // loads per lane
+    unsigned v[NL];
+    int shift;
+    __device__ inline void issue(const uint8_t* src, int pitch, int rows, int nbytes, int lane) {
+        const unsigned long long a0 = (unsigned long long)src;
+        shift = (int)(a0 & 3ull);
+        const unsigned* base = (const unsigned*)(a0 - shift);
+        const int nd = (shift + nbytes + 3) >> 2;  // dwords per row actually needed (<= LDP)
+        const int pd = pitch >> 2;
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int e = lane + 64 * q, r = e / LDP, c = e % LDP;
+            // clamped instead of predicated: every load is unconditional and in flight with the others
+            v[q] = base[(size_t)min(r, rows - 1) * pd + min(c, nd - 1)];
+        }
+    }
+    __device__ inline void commit(unsigned* lds, int lane) const {
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int e = lane + 64 * q;
+            if (e < MAXR * LDP) lds[e] = v[q];
+        }
+    }
+};
+
+#define KLT_TW (KLT_MAX_WIN + 1)                 // template rows / columns incl. the bilinear neighbour (22)
+#define KLT_TIP 8                                // dwords per LDS row of the template image (22 + 3 bytes -> 7)
+#define KLT_JP 11                                // dwords per LDS row of the search region (38 + 3 bytes -> 11)
+
 // One wavefront per point.  Mirrors LKTrackerInvoker; every scalar expression is evaluated
-// redundantly (and identically) by all 64 lanes.
+// redundantly (and identically) by all 64 lanes.  Per level everything the wavefront reads from memory
+// (template image, its derivatives, the search region) is fetched with aligned 4-byte loads into LDS first;
+// the per-pixel work then runs out of LDS.
 __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, const float* __restrict__ prev_px,
                                                        float* next_px, uint8_t* status, int n, int win, int max_iter,
-                                                       float eps2, float min_eig) {
-    __shared__ uint8_t reg[KLT_RS * KLT_RP];
+                                                       float eps2, float min_eig, long long* dbg) {
+#define KSTAMP(slot)                                                                                   \
+    do {                                                                                               \
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[900 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    KSTAMP(0);
+    __shared__ unsigned regJ[KLT_RS * KLT_JP];         // search region of J, rows of aligned dwords
+    __shared__ unsigned regI[KLT_TW * KLT_TIP];        // template image rows
+    __shared__ unsigned regD[KLT_TW * KLT_TW];         // template derivatives, one (dx,dy) short pair per pixel
+    const uint8_t* regJb = (const uint8_t*)regJ;
+    const uint8_t* regIb = (const uint8_t*)regI;
     const int pt = blockIdx.x;
     const int lane = threadIdx.x;
     if (pt >= n) return;
@@ -130,8 +184,10 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
     for (int t = 0; t < KLT_SLOTS; t++) {
         const int s = lane + 64 * t;
         sv[t] = s < npix;
-        sx[t] = sv[t] ? s % win : 0;
-        sy[t] = sv[t] ? s / win : 0;
+        // s / win by reciprocal multiplication: exact for s < 448 and every odd window 3..21 (checked exhaustively)
+        const int q = (s * (65536 / win + 1)) >> 16;
+        sx[t] = sv[t] ? s - q * win : 0;
+        sy[t] = sv[t] ? q : 0;
     }
     const float ppx0 = prev_px[2 * pt], ppy0 = prev_px[2 * pt + 1];
     float ox = next_px[2 * pt], oy = next_px[2 * pt + 1];
@@ -155,32 +211,60 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
             if (level == 0) ok = false;
             continue;
         }
+        KSTAMP(1 + 8 * level);
+        // ---- one batch of aligned loads: template image, template derivatives, first search region ----
+        float nx = ox - half, ny = oy - half;
+        int rx0 = 0, ry0 = 0, shJ = 0;
+        bool staged = false;
+        __syncthreads();  // previous level's LDS readers are done
+        const size_t o0 = (size_t)(ipy + KLT_BORDER) * I.pitch + (ipx + KLT_BORDER);
+        RowStage<KLT_TW, KLT_TIP> stI;
+        RowStage<KLT_TW, KLT_TW> stD;
+        RowStage<KLT_RS, KLT_JP> stJ;
+        stI.issue(I.img + o0, I.pitch, win + 1, win + 1, lane);
+        stD.issue((const uint8_t*)(I.der + o0 * 2), I.pitch * 4, win + 1, 4 * (win + 1), lane);  // one dword per pixel
+        {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (!(inx < -win || inx >= J.w || iny < -win || iny >= J.h)) {
+                rx0 = min(max(inx - KLT_R, -KLT_BORDER), J.w + KLT_BORDER - KLT_RS);
+                ry0 = min(max(iny - KLT_R, -KLT_BORDER), J.h + KLT_BORDER - KLT_RS);
+                staged = true;
+            }
+        }
+        // (when the start point is outside J nothing will be read from regJ: the iteration loop leaves first)
+        stJ.issue(J.img + (size_t)(ry0 + KLT_BORDER) * J.pitch + rx0 + KLT_BORDER, J.pitch, KLT_RS, KLT_RS, lane);
+        stI.commit(regI, lane);
+        stD.commit(regD, lane);
+        stJ.commit(regJ, lane);
+        const int shI = stI.shift;
+        shJ = stJ.shift;
+        __syncthreads();
+        KSTAMP(2 + 8 * level);
         float a = ppx - ipx, b = ppy - ipy;
         int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << W_BITS));
         int iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
         int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int Iv[KLT_SLOTS], Ix[KLT_SLOTS], Iy[KLT_SLOTS];
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
+        int pA11 = 0, pA12 = 0, pA22 = 0;  // per-lane partials: 7 terms of at most 4080^2 each
 #pragma unroll
         for (int t = 0; t < KLT_SLOTS; t++) {
-            Iv[t] = Ix[t] = Iy[t] = 0;
-            if (sv[t]) {
-                const size_t o = (size_t)(ipy + sy[t] + KLT_BORDER) * I.pitch + (ipx + sx[t] + KLT_BORDER);
-                const uint8_t* ip = I.img + o;
-                const short* dp = I.der + o * 2;
-                Iv[t] = descale(ip[0] * iw00 + ip[1] * iw01 + ip[I.pitch] * iw10 + ip[I.pitch + 1] * iw11, W_BITS - 5);
-                const int dpn = I.pitch * 2;
-                Ix[t] = descale(dp[0] * iw00 + dp[2] * iw01 + dp[dpn] * iw10 + dp[dpn + 2] * iw11, W_BITS);
-                Iy[t] = descale(dp[1] * iw00 + dp[3] * iw01 + dp[dpn + 1] * iw10 + dp[dpn + 3] * iw11, W_BITS);
-                sA11 += (long long)Ix[t] * Ix[t];
-                sA12 += (long long)Ix[t] * Iy[t];
-                sA22 += (long long)Iy[t] * Iy[t];
+            {   // slots past the window read pixel (0,0) and are zeroed below: no branch, all LDS reads in one batch
+                const uint8_t* ip = regIb + sy[t] * (KLT_TIP * 4) + shI + sx[t];
+                Iv[t] = descale(ip[0] * iw00 + ip[1] * iw01 + ip[KLT_TIP * 4] * iw10 + ip[KLT_TIP * 4 + 1] * iw11, W_BITS - 5);
+                const unsigned d00 = regD[sy[t] * KLT_TW + sx[t]], d01 = regD[sy[t] * KLT_TW + sx[t] + 1];
+                const unsigned d10 = regD[(sy[t] + 1) * KLT_TW + sx[t]], d11 = regD[(sy[t] + 1) * KLT_TW + sx[t] + 1];
+                Ix[t] = descale((short)(d00 & 0xffff) * iw00 + (short)(d01 & 0xffff) * iw01 + (short)(d10 & 0xffff) * iw10 +
+                                    (short)(d11 & 0xffff) * iw11, W_BITS);
+                Iy[t] = descale((short)(d00 >> 16) * iw00 + (short)(d01 >> 16) * iw01 + (short)(d10 >> 16) * iw10 +
+                                    (short)(d11 >> 16) * iw11, W_BITS);
+                if (!sv[t]) Iv[t] = Ix[t] = Iy[t] = 0;
+                pA11 += Ix[t] * Ix[t];
+                pA12 += Ix[t] * Iy[t];
+                pA22 += Iy[t] * Iy[t];
             }
         }
-        sA11 = wave_sum(sA11);
-        sA12 = wave_sum(sA12);
-        sA22 = wave_sum(sA22);
+        const long long sA11 = wave_sum_i32(pA11), sA12 = wave_sum_i32(pA12), sA22 = wave_sum_i32(pA22);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
@@ -189,10 +273,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
             continue;
         }
         D = 1.f / D;
-        float nx = ox - half, ny = oy - half;
+        KSTAMP(3 + 8 * level);
         float pdx = 0.f, pdy = 0.f;
-        int rx0 = 0, ry0 = 0;
-        bool staged = false;
+        int itc = 0;
         for (int j = 0; j < max_iter; j++) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
@@ -204,10 +287,10 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
                 rx0 = min(max(inx - KLT_R, -KLT_BORDER), J.w + KLT_BORDER - KLT_RS);
                 ry0 = min(max(iny - KLT_R, -KLT_BORDER), J.h + KLT_BORDER - KLT_RS);
                 __syncthreads();
-                for (int e = lane; e < KLT_RS * KLT_RS; e += 64) {
-                    const int ry = e / KLT_RS, rx = e % KLT_RS;
-                    reg[ry * KLT_RP + rx] = J.img[(size_t)(ry0 + ry + KLT_BORDER) * J.pitch + rx0 + rx + KLT_BORDER];
-                }
+                RowStage<KLT_RS, KLT_JP> st2;
+                st2.issue(J.img + (size_t)(ry0 + KLT_BORDER) * J.pitch + rx0 + KLT_BORDER, J.pitch, KLT_RS, KLT_RS, lane);
+                st2.commit(regJ, lane);
+                shJ = st2.shift;
                 __syncthreads();
                 staged = true;
             }
@@ -217,20 +300,20 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
             iw01 = __float2int_rn(a * (1.f - b) * (1 << W_BITS));
             iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            long long sb1 = 0, sb2 = 0;
-            const int bx = inx - rx0, by = iny - ry0;
+            int pb1 = 0, pb2 = 0;  // per-lane partials: 7 terms of at most 8160 * 4080 each
+            const int bx = inx - rx0 + shJ, by = iny - ry0;
 #pragma unroll
             for (int t = 0; t < KLT_SLOTS; t++) {
-                if (sv[t]) {
-                    const uint8_t* jp = reg + (by + sy[t]) * KLT_RP + bx + sx[t];
+                {   // Ix = Iy = 0 in the slots past the window: their terms vanish
+                    const uint8_t* jp = regJb + (by + sy[t]) * (KLT_JP * 4) + bx + sx[t];
                     const int diff =
-                        descale(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_RP] * iw10 + jp[KLT_RP + 1] * iw11, W_BITS - 5) - Iv[t];
-                    sb1 += (long long)diff * Ix[t];
-                    sb2 += (long long)diff * Iy[t];
+                        descale(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_JP * 4] * iw10 + jp[KLT_JP * 4 + 1] * iw11, W_BITS - 5) - Iv[t];
+                    pb1 += diff * Ix[t];
+                    pb2 += diff * Iy[t];
                 }
             }
-            sb1 = wave_sum(sb1);
-            sb2 = wave_sum(sb2);
+            const long long sb1 = wave_sum_i32(pb1), sb2 = wave_sum_i32(pb2);
+            itc++;
             const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
@@ -247,6 +330,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
             pdx = dx;
             pdy = dy;
         }
+        KSTAMP(4 + 8 * level);
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[900 + 5 + 8 * level] = itc;
         if (ok && level == 0) {
             const int fx = (int)floorf(ox - half), fy = (int)floorf(oy - half);
             if (fx < -win || fx >= J.w || fy < -win || fy >= J.h) ok = false;
@@ -329,7 +414,8 @@ int klt_alloc(ekfvio_filter* f) {
     for (int fr = 0; fr < 2; fr++) {
         int w = c.max_image_width, h = c.max_image_height;
         for (int l = 0; l <= c.klt_max_pyramid_level; l++) {
-            const size_t px = (size_t)level_pitch(w) * (h + 2 * KLT_BORDER);
+            // + one row of slack: the tracker's aligned 4-byte loads may touch up to 3 bytes past a row's last pixel
+            const size_t px = (size_t)level_pitch(w) * (h + 2 * KLT_BORDER + 1);
             HIPK(f, hipMalloc((void**)&f->frames[fr].img[l], px));
             HIPK(f, hipMalloc((void**)&f->frames[fr].deriv[l], px * 2 * sizeof(short)));
             HIPK(f, hipMemsetAsync(f->frames[fr].img[l], 0, px, f->stream));
@@ -410,7 +496,7 @@ static int track_points_device(ekfvio_filter* f, int n) {
     ProfScope ps(f, PC_KLT_TRACK);
     hipLaunchKernelGGL(klt_track_kernel, dim3(n), dim3(64), 0, f->stream, make_view(prev), make_view(cur), f->klt_prev_px,
                        f->klt_next_px, f->klt_status, n, f->cfg.klt_window_size, f->cfg.klt_max_iterations, eps * eps,
-                       f->cfg.klt_min_eigen);
+                       f->cfg.klt_min_eigen, f->sweep_dbg);
     return EKFVIO_OK;
 }
 
