@@ -591,12 +591,11 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
     HIPC(f, hipMemcpyAsync(dC, hC.data(), sizeof(float) * hC.size(), hipMemcpyHostToDevice, f->stream));
     const bool stamped = variant >= 10000;  // library built with -DEKF_GEMM_STAMPS
     variant %= 10000;
-    const int dbgf = 0;
     for (int w = 0; w < 3; w++)
-        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, dbgf, lowerB);
+        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
     HIPC(f, hipEventRecord(f->ev0, f->stream));
     for (int r = 0; r < reps; r++)
-        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, dbgf, lowerB);
+        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
     HIPC(f, hipEventRecord(f->ev1, f->stream));
     HIPC(f, hipEventSynchronize(f->ev1));
     float ms = 0;
@@ -606,7 +605,7 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
         long long* dst;
         HIPC(f, dev_alloc(f->stream, &dst, 40));
         gemm_set_stamp_buffer(dst);
-        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, dbgf, lowerB);
+        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
         long long hst[40];
         HIPC(f, hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, f->stream));
         HIPC(f, hipStreamSynchronize(f->stream));

@@ -493,12 +493,9 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
         if constexpr (BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 2 * BKS * SB]) = S##b2;         \
         if constexpr (BV > 2) *reinterpret_cast<float4*>(&Bs[buf][bl + 3 * BKS * SB]) = S##b3;         \
     } while (0)
-#ifdef EKF_G16_ASM_MFMA
-#define G16_MFMA(c, b, a) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(b), "v"(a))
-#else
 #define G16_MFMA(c, b, a) c = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, c, 0, 0, 0)
-#endif
-// timing experiments only (results are wrong with any of these set): -DG16X_NOLOAD=1 ...
+// compile-time switches for pricing the parts of the K loop (scripts/gemm_loop_pricing.sh); the results are wrong
+// with any of them set: -DG16X_NOLOAD=1 -DG16X_NOSTAGE=1 -DG16X_NOBAR=1 -DG16X_NOFR=1
 #ifndef G16X_NOLOAD
 #define G16X_NOLOAD 0
 #endif
@@ -579,9 +576,6 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             GSTAMP(3 + t);
         }
         if (t < KT) G16_TILE(X, Y, t);
-#ifdef EKF_G16_ASM_MFMA
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
         GSTAMP(36);
         __syncthreads();  // every wavefront is done with LDS (the reduction below reuses it)
     }
