@@ -437,12 +437,14 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             }
         }
     }
-    // Two staging register sets, X and Y, alternate between iterations (tile t+1 sits in one while
-    // tile t+2 is loaded into the other).  With a single set hipcc loads into fresh registers and
+    // Three staging register sets, X, Y and Z, rotate between iterations (tile t+1 sits in one, tile t+2 is in
+    // flight into the second, tile t+3 is requested into the third).  With a single set hipcc loads into fresh registers and
     // copies them back at the loop edge, which parks a full memory round trip behind every K-tile.
     float4 Xa0, Xa1, Xa2, Xa3, Xb0, Xb1, Xb2, Xb3, Ya0, Ya1, Ya2, Ya3, Yb0, Yb1, Yb2, Yb3;
+    float4 Za0, Za1, Za2, Za3, Zb0, Zb1, Zb2, Zb3;
     Xa0 = Xa1 = Xa2 = Xa3 = Xb0 = Xb1 = Xb2 = Xb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     Ya0 = Ya1 = Ya2 = Ya3 = Yb0 = Yb1 = Yb2 = Yb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Za0 = Za1 = Za2 = Za3 = Zb0 = Zb1 = Zb2 = Zb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define G16_LOAD(S, kt)                                                                                \
     do {                                                                                               \
         const int sa_ = a_base + (kt) * a_step, sb_ = b_base + (kt) * b_step;                          \
@@ -517,8 +519,8 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     // One K-tile t out of LDS buffer t % 3.  Per wavefront NS k-steps (every WPS-th of the tile); a
     // step's operand fragments are read two steps ahead, for steps 0 and 1 already during the
     // previous tile.  Around the MFMAs of
-    //   steps 0..BAR-1  one global load of tile t+2 (register set S2) and one LDS write of tile t+1
-    //               (register set S1, loaded a whole tile ago, to buffer (t+1) % 3) per step,
+    //   steps 0..BAR-1  one global load of tile t+3 (register set S2) and one LDS write of tile t+1
+    //               (register set S1, loaded two tiles ago, to buffer (t+1) % 3) per step,
     //   step BAR    the one barrier of the tile: tile t+1 is visible from here on, and every wavefront
     //               is done with buffer (t-1) % 3, the target of the NEXT tile's staging,
     //   steps NS-2, NS-1  the first two fragment sets of tile t+1 are fetched,
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
                behind the CU's 64 B/clk vector-memory path and the MFMAs queue up behind it);         \
                past the last tile the loads fall outside the buffer (zeros, no traffic) and what is   \
                staged is never read: a branch here would split the pinned instruction stream */       \
-            if (!G16X_NOLOAD) G16_LOADI(S2, st, (tcur) + 2);                              \
+            if (!G16X_NOLOAD) G16_LOADI(S2, st, (tcur) + 3);                              \
             if (!G16X_NOSTAGE) G16_STAGEI(S1, st, nxt);                                   \
             if (st == BAR && !G16X_NOBAR) __syncthreads();                                \
             if (st == NS - 2) G16_FR(n, 0, 0);                                            \
@@ -553,11 +555,14 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     if (KT > 0) {
         constexpr int BAR = AV + BV;  // the step after the last staging write
         static_assert(BAR <= NS - 3 && NS % 4 == 0, "step schedule");
-        // tiles 0 and 1 are requested together (one memory round trip instead of two)
-        G16_LOAD(Y, 0);
+        // tiles 0, 1 and 2 are requested together (one memory round trip); from then on tile t+3 is requested while
+        // tile t is computed and written to LDS during tile t+2: two tile times of memory latency are covered, which
+        // a full grid needs (every XCD's first touch of an operand panel comes from the fabric, not from its L2)
+        G16_LOAD(Z, 0);
         G16_LOAD(X, 1);
-        G16_STAGE_A(Y, 0);
-        G16_STAGE_B(Y, 0);
+        G16_LOAD(Y, 2);
+        G16_STAGE_A(Z, 0);
+        G16_STAGE_B(Z, 0);
         __syncthreads();
         float fa[4][RB], fb[4];
         int cb = 0;
@@ -569,13 +574,20 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
         G16_FR(n, 1, 1);
         GSTAMP(1);
         int t = 0;
-        for (; t + 1 < KT; t += 2) {
-            G16_TILE(X, Y, t);
+        // register sets rotate: (stage, in flight, load) = (X, Y, Z) -> (Y, Z, X) -> (Z, X, Y)
+        for (; t + 2 < KT; t += 3) {
+            G16_TILE(X, Z, t);
             GSTAMP(2 + t);
             G16_TILE(Y, X, t + 1);
             GSTAMP(3 + t);
+            G16_TILE(Z, Y, t + 2);
+            GSTAMP(4 + t);
         }
-        if (t < KT) G16_TILE(X, Y, t);
+        if (t < KT) {
+            G16_TILE(X, Z, t);
+            t++;
+        }
+        if (t < KT) G16_TILE(Y, X, t);
         GSTAMP(36);
         __syncthreads();  // every wavefront is done with LDS (the reduction below reuses it)
     }
