@@ -156,7 +156,10 @@ __device__ __forceinline__ f32x4 mma16(const float* As, int a_si, int a_sq, cons
 // B operand is read from LDS with the matching k permutation), so the dependent chain is
 // MFMA -> MFMA with no LDS round trip; all B operands are preloaded.
 template <int NT>
-__device__ __forceinline__ void tri_solve_fwd_n(float* const (&Txs)[NT], const float* Tl, const float* Tinv, int wave, int lane) {
+__device__ __forceinline__ void tri_solve_fwd_n(float* const (&Txs)[NT], const float* Tl, const float* Tinv, int wave, int lane,
+                                                long long* st = nullptr) {
+#define TSTAMP(i) do { if (st && wave == 0 && lane == 0) st[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    TSTAMP(0);
     const int r0 = 16 * wave, li = lane & 15, g = lane >> 4;
     f32x4 x[NT][4];
     float binv[4][4];   // Inv_p(li, 4g+v)
@@ -190,6 +193,7 @@ __device__ __forceinline__ void tri_solve_fwd_n(float* const (&Txs)[NT], const f
     for (int q = 0; q < 6; q++)
 #pragma unroll
         for (int v = 0; v < 4; v++) asm volatile("" : "+v"(nl[q][v]));
+    TSTAMP(1);
     int e0 = 0;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -212,16 +216,18 @@ __device__ __forceinline__ void tri_solve_fwd_n(float* const (&Txs)[NT], const f
                 for (int n = 0; n < NT; n++) x[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(nl[e][v], y[n][v], x[n][t], 0, 0, 0);
         e0 = e;
     }
+    TSTAMP(2);
 #pragma unroll
     for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int v = 0; v < 4; v++) Txs[n][(16 * b + 4 * g + v) * PLD + r0 + li] = x[n][b][v];
+    TSTAMP(3);
 }
-__device__ __forceinline__ void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane) {
+__device__ __forceinline__ void tri_solve_fwd(float* Tx, const float* Tl, const float* Tinv, int wave, int lane, long long* st = nullptr) {
     float* const t[1] = {Tx};
-    tri_solve_fwd_n<1>(t, Tl, Tinv, wave, lane);
+    tri_solve_fwd_n<1>(t, Tl, Tinv, wave, lane, st);
 }
 __device__ __forceinline__ void tri_solve_fwd2(float* Tx, float* Ty, const float* Tl, const float* Tinv, int wave, int lane) {
     float* const t[2] = {Tx, Ty};
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     if (i != j)
         tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
     else
-        tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
+        tri_solve_fwd(Ti, Tl, Tinv, wave, lane, (dbg && blockIdx.x == 0) ? dbg + 960 + 4 * k : nullptr);
     __syncthreads();
     CSTAMP(2);
     if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
