@@ -420,3 +420,32 @@ def test_profile_update_gemms_leaves_state_untouched():
         g.close()
     for key in ("base_mu", "feat_mu", "Sigma"):
         assert np.array_equal(runs[0][key], runs[1][key]), key
+
+
+def test_persistent_sweep_matches_per_step_sweep(monkeypatch):
+    """EKFVIO_SWEEP=1 selects the single-launch sweep (chain workgroup + helpers handing tiles over through
+    write-through stores and flags): same device functions in the same order, so the same bits as one launch per
+    block step, for the raw factorisation and for a filter update."""
+    rng = np.random.default_rng(7)
+    m, nr = 200, 150
+    Q = rng.standard_normal((m, m))
+    S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
+    Cr = rng.standard_normal((nr, m)).astype(np.float32)
+    N = 48
+    sc = Scenario(N, seed=2)
+    fr = list(sc.frames(3))
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EKFVIO_SWEEP", mode)
+        g = TightlyCoupledEKF(max_features=N)
+        L, X, info = g.test_cholesky_solve(S, Cr)
+        assert info == 0
+        g.addNewFeatures(sc.initial_features())
+        for z, R, p in fr:
+            g.process(sc.dt)
+            assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+        res.append((np.tril(L), X, g.get_state()))
+        g.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for key in ("base_mu", "feat_mu", "Sigma"):
+        assert np.array_equal(res[0][2][key], res[1][2][key]), key
