@@ -62,42 +62,41 @@ __device__ __host__ inline int reflect101(int p, int len) {
     return p;
 }
 
-__global__ void klt_pad_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, uint8_t* dst, int pitch) {
+// One pyramid level in ONE launch: the padded image (reflect-101 border) and the Scharr derivatives of its
+// interior.  FIRST: level 0 from the frame itself; otherwise pyrDown of the previous padded level.  An interior
+// thread evaluates the level's pixel at its 3x3 neighbourhood itself (up to 9 x 25 taps: cheaper than a second
+// launch that re-reads the level), so a four-level pyramid is four launches instead of eight (pad, pyrDown x3,
+// Scharr x4).  pyrDown: [1 4 6 4 1]^2 / 256 with (v + 128) >> 8, BORDER_REFLECT_101 (the source level's border
+// supplies it); Scharr: 3/10/3, int16, zero outside the image.
+template <bool FIRST>
+__global__ void klt_level_kernel(const uint8_t* __restrict__ src, int spitch, uint8_t* __restrict__ dst, short* __restrict__ der, int w,
+                                 int h, int pitch) {
     const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
     if (X >= w + 2 * KLT_BORDER) return;
-    const int x = reflect101(X - KLT_BORDER, w), y = reflect101(Y - KLT_BORDER, h);
-    dst[(size_t)Y * pitch + X] = src[(size_t)y * stride + x];
-}
-
-// pyrDown: [1 4 6 4 1]^2 / 256 with (v + 128) >> 8, BORDER_REFLECT_101 (the source border)
-__global__ void klt_pyrdown_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch, uint8_t* dst, int dw,
-                                   int dh, int dpitch) {
-    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
-    if (X >= dw + 2 * KLT_BORDER) return;
-    const int x = reflect101(X - KLT_BORDER, dw), y = reflect101(Y - KLT_BORDER, dh);
-    const uint8_t* s = src + (size_t)(2 * y + KLT_BORDER) * spitch + 2 * x + KLT_BORDER;
-    int v = 0;
+    auto val = [&](int xx, int yy) -> int {  // the level's pixel at reflect-101 coordinates
+        const int x = reflect101(xx, w), y = reflect101(yy, h);
+        if (FIRST) return src[(size_t)y * spitch + x];
+        const uint8_t* s = src + (size_t)(2 * y + KLT_BORDER) * spitch + 2 * x + KLT_BORDER;
+        int v = 0;
 #pragma unroll
-    for (int j = -2; j <= 2; j++) {
-        const uint8_t* r = s + j * spitch;
-        const int rs = r[-2] + r[2] + 4 * (r[-1] + r[1]) + 6 * r[0];
-        const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
-        v += wj * rs;
-    }
-    dst[(size_t)Y * dpitch + X] = (uint8_t)((v + 128) >> 8);
-    (void)sw;
-    (void)sh;
-}
-
-// Scharr derivatives of the level interior; the derivative border stays zero.
-__global__ void klt_scharr_kernel(const uint8_t* __restrict__ img, int w, int h, int pitch, short* der) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const uint8_t* c = img + (size_t)(y + KLT_BORDER) * pitch + x + KLT_BORDER;
-    const uint8_t *u = c - pitch, *d = c + pitch;
-    const int t0m = (u[-1] + d[-1]) * 3 + c[-1] * 10, t0p = (u[1] + d[1]) * 3 + c[1] * 10;
-    const int t1m = d[-1] - u[-1], t1c = d[0] - u[0], t1p = d[1] - u[1];
-    short* o = der + ((size_t)(y + KLT_BORDER) * pitch + x + KLT_BORDER) * 2;
+        for (int j = -2; j <= 2; j++) {
+            const uint8_t* r = s + j * spitch;
+            const int rs = r[-2] + r[2] + 4 * (r[-1] + r[1]) + 6 * r[0];
+            const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+            v += wj * rs;
+        }
+        return (v + 128) >> 8;
+    };
+    const int x = X - KLT_BORDER, y = Y - KLT_BORDER;
+    const int c11 = val(x, y);
+    dst[(size_t)Y * pitch + X] = (uint8_t)c11;
+    if (x < 0 || x >= w || y < 0 || y >= h) return;
+    const int u0 = val(x - 1, y - 1), u1 = val(x, y - 1), u2 = val(x + 1, y - 1);
+    const int c0 = val(x - 1, y), c2 = val(x + 1, y);
+    const int d0 = val(x - 1, y + 1), d1 = val(x, y + 1), d2 = val(x + 1, y + 1);
+    const int t0m = (u0 + d0) * 3 + c0 * 10, t0p = (u2 + d2) * 3 + c2 * 10;
+    const int t1m = d0 - u0, t1c = d1 - u1, t1p = d2 - u2;
+    short* o = der + ((size_t)Y * pitch + X) * 2;
     o[0] = (short)(t0p - t0m);
     o[1] = (short)((t1p + t1m) * 3 + t1c * 10);
 }
@@ -458,20 +457,15 @@ static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int
         fr.levels = l + 1;
     }
     ProfScope ps(f, PC_KLT_PYRAMID);
-    {
-        const int pw = w + 2 * KLT_BORDER, ph = h + 2 * KLT_BORDER;
-        hipLaunchKernelGGL(klt_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, f->stream, src, w, h, w,
-                           fr.img[0], level_pitch(w));
-    }
-    for (int l = 1; l < fr.levels; l++) {
+    for (int l = 0; l < fr.levels; l++) {
         const int pw = fr.w[l] + 2 * KLT_BORDER, ph = fr.h[l] + 2 * KLT_BORDER;
-        hipLaunchKernelGGL(klt_pyrdown_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, f->stream, fr.img[l - 1],
-                           fr.w[l - 1], fr.h[l - 1], level_pitch(fr.w[l - 1]), fr.img[l], fr.w[l], fr.h[l],
-                           level_pitch(fr.w[l]));
+        const dim3 grid((pw + 255) / 256, ph);
+        if (l == 0)
+            hipLaunchKernelGGL(klt_level_kernel<true>, grid, dim3(256), 0, f->stream, src, w, fr.img[0], fr.deriv[0], w, h, level_pitch(w));
+        else
+            hipLaunchKernelGGL(klt_level_kernel<false>, grid, dim3(256), 0, f->stream, fr.img[l - 1], level_pitch(fr.w[l - 1]), fr.img[l],
+                               fr.deriv[l], fr.w[l], fr.h[l], level_pitch(fr.w[l]));
     }
-    for (int l = 0; l < fr.levels; l++)
-        hipLaunchKernelGGL(klt_scharr_kernel, dim3((fr.w[l] + 255) / 256, fr.h[l]), dim3(256), 0, f->stream, fr.img[l],
-                           fr.w[l], fr.h[l], level_pitch(fr.w[l]), fr.deriv[l]);
     return EKFVIO_OK;
 }
 
