@@ -250,17 +250,20 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
         for (int t = 0; t < KLT_SLOTS; t++) {
             {   // slots past the window read pixel (0,0) and are zeroed below: no branch, all LDS reads in one batch
                 const uint8_t* ip = regIb + sy[t] * (KLT_TIP * 4) + shI + sx[t];
-                Iv[t] = descale(ip[0] * iw00 + ip[1] * iw01 + ip[KLT_TIP * 4] * iw10 + ip[KLT_TIP * 4 + 1] * iw11, W_BITS - 5);
+                // every factor fits 24 bits (pixels <= 255, weights <= 2^14, derivatives <= 4080, differences <= 8160):
+                // v_mul_i32_i24 / v_mad_i32_i24 run at full rate, v_mul_lo_u32 (what `*` compiles to) at a quarter
+                Iv[t] = descale(__mul24(ip[0], iw00) + __mul24(ip[1], iw01) + __mul24(ip[KLT_TIP * 4], iw10) +
+                                    __mul24(ip[KLT_TIP * 4 + 1], iw11), W_BITS - 5);
                 const unsigned d00 = regD[sy[t] * KLT_TW + sx[t]], d01 = regD[sy[t] * KLT_TW + sx[t] + 1];
                 const unsigned d10 = regD[(sy[t] + 1) * KLT_TW + sx[t]], d11 = regD[(sy[t] + 1) * KLT_TW + sx[t] + 1];
-                Ix[t] = descale((short)(d00 & 0xffff) * iw00 + (short)(d01 & 0xffff) * iw01 + (short)(d10 & 0xffff) * iw10 +
-                                    (short)(d11 & 0xffff) * iw11, W_BITS);
-                Iy[t] = descale((short)(d00 >> 16) * iw00 + (short)(d01 >> 16) * iw01 + (short)(d10 >> 16) * iw10 +
-                                    (short)(d11 >> 16) * iw11, W_BITS);
+                Ix[t] = descale(__mul24((short)(d00 & 0xffff), iw00) + __mul24((short)(d01 & 0xffff), iw01) +
+                                    __mul24((short)(d10 & 0xffff), iw10) + __mul24((short)(d11 & 0xffff), iw11), W_BITS);
+                Iy[t] = descale(__mul24((short)(d00 >> 16), iw00) + __mul24((short)(d01 >> 16), iw01) +
+                                    __mul24((short)(d10 >> 16), iw10) + __mul24((short)(d11 >> 16), iw11), W_BITS);
                 if (!sv[t]) Iv[t] = Ix[t] = Iy[t] = 0;
-                pA11 += Ix[t] * Ix[t];
-                pA12 += Ix[t] * Iy[t];
-                pA22 += Iy[t] * Iy[t];
+                pA11 += __mul24(Ix[t], Ix[t]);
+                pA12 += __mul24(Ix[t], Iy[t]);
+                pA22 += __mul24(Iy[t], Iy[t]);
             }
         }
         const long long sA11 = wave_sum_i32(pA11), sA12 = wave_sum_i32(pA12), sA22 = wave_sum_i32(pA22);
@@ -305,10 +308,10 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
             for (int t = 0; t < KLT_SLOTS; t++) {
                 {   // Ix = Iy = 0 in the slots past the window: their terms vanish
                     const uint8_t* jp = regJb + (by + sy[t]) * (KLT_JP * 4) + bx + sx[t];
-                    const int diff =
-                        descale(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_JP * 4] * iw10 + jp[KLT_JP * 4 + 1] * iw11, W_BITS - 5) - Iv[t];
-                    pb1 += diff * Ix[t];
-                    pb2 += diff * Iy[t];
+                    const int diff = descale(__mul24(jp[0], iw00) + __mul24(jp[1], iw01) + __mul24(jp[KLT_JP * 4], iw10) +
+                                                 __mul24(jp[KLT_JP * 4 + 1], iw11), W_BITS - 5) - Iv[t];
+                    pb1 += __mul24(diff, Ix[t]);
+                    pb2 += __mul24(diff, Iy[t]);
                 }
             }
             const long long sb1 = wave_sum_i32(pb1), sb2 = wave_sum_i32(pb2);
