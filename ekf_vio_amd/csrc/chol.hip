@@ -397,6 +397,11 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
 // grid.x = r(r+1)/2 triangular tiles of A (r = mb-1-k) + rb*r rectangular tiles of the extra
 // row blocks (X: the forward substitution Y L^T = X rides along; I: yields L^-T).
 // idb0 = first identity row block: its block row q is still zero left of column block q.
+// SOLVE = true: every tile workgroup forms the two panel blocks it needs itself (one launch per block step: the
+// latency-optimal form for few tiles).  SOLVE = false: the panel blocks L_ik were written by chol_panel_kernel(k)
+// before (two launches per block step): with thousands of tiles per step (N = 1024: mb = 32) the per-tile panel
+// solves are 60 % redundant work.
+template <bool SOLVE>
 __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
                                                         float* __restrict__ Linv, int k, int mb, int idb0, int* info,
                                                         long long* dbg) {
@@ -427,19 +432,25 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         if (i >= idb0 && i - idb0 > k) return;  // identity block row: block (i,k) is still zero
     }
 
-    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
-    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
-    load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
-    if (i != j) load_tile(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
-    __syncthreads();
-    CSTAMP(1);
-    if (i != j)
-        tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
-    else
-        tri_solve_fwd(Ti, Tl, Tinv, wave, lane, (dbg && blockIdx.x == 0) ? dbg + 960 + 4 * k : nullptr);
-    __syncthreads();
-    CSTAMP(2);
-    if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+    if (SOLVE) {
+        load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
+        load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
+        load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
+        if (i != j) load_tile(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
+        __syncthreads();
+        CSTAMP(1);
+        if (i != j)
+            tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
+        else
+            tri_solve_fwd(Ti, Tl, Tinv, wave, lane, (dbg && blockIdx.x == 0) ? dbg + 960 + 4 * k : nullptr);
+        __syncthreads();
+        CSTAMP(2);
+        if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+    } else {
+        load_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+        if (i != j) load_tile(Tj, L + (size_t)k * PB * ldl + (size_t)j * PB, ldl, tid);
+        __syncthreads();
+    }
     // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
     const float* Bj = (i != j) ? Tj : Ti;
     const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
@@ -469,14 +480,17 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
 }
 
-// X_k <- X_k L_kk^-T for the extra row blocks at the last block column (no trailing tiles left)
-__global__ __launch_bounds__(256) void chol_last_panel_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
-                                                              int ldl, const float* __restrict__ Linv, int k, int mb) {
+// Block column k of the panel: L_ik = A_ik L_kk^-T for the row blocks below the diagonal (A rows k+1 .. mb-1, `na` of
+// them; na = 0 for the last block column) and the extra row blocks (X, I).
+__global__ __launch_bounds__(256) void chol_panel_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
+                                                         int ldl, const float* __restrict__ Linv, int k, int mb, int na, int idb0) {
     __shared__ float Ti[PB * PLD];
     __shared__ float Tl[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = mb + blockIdx.x;
+    const int b = blockIdx.x;
+    const int i = (b < na) ? k + 1 + b : mb + (b - na);
+    if (i >= idb0 && i - idb0 > k) return;  // identity block row: block (i,k) is still zero and stays unused
     load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
     load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
     load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
@@ -560,6 +574,7 @@ __device__ __forceinline__ void store_inv_coh(const float* Tinv, float* G, int t
 // (the result is then garbage and info bit 1 is set), so the grid always drains.
 // Requires gridDim.x <= number of CUs (one resident workgroup per CU).
 #define SWEEP_SPIN_LIMIT (1 << 22)
+
 
 __device__ __forceinline__ void sweep_wait(int* flag, int target, int* abort_flag, int* info, int tid) {
     if (tid == 0) {
@@ -767,12 +782,21 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         return;
     }
     hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info);
+    // many tiles per step: panel blocks once per step in a launch of their own instead of twice per tile
+    const bool split = mb >= EKF_SWEEP_SPLIT_MB;
     for (int k = 0; k + 1 < mb; k++) {
         const int r = mb - 1 - k;
-        hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2 + rb * r), dim3(256), 0, f->stream, Saug, ld, Laug, ld,
-                           Linv, k, mb, idb0, f->info, f->sweep_dbg);
+        const dim3 grid(r * (r + 1) / 2 + rb * r);
+        if (split) {
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(r + rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, r, idb0);
+            hipLaunchKernelGGL(chol_step_kernel<false>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
+                               f->sweep_dbg);
+        } else {
+            hipLaunchKernelGGL(chol_step_kernel<true>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
+                               f->sweep_dbg);
+        }
     }
-    hipLaunchKernelGGL(chol_last_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0);
 }
 
 // K = X A^-1 = Y L^-1 with Y = X L^-T and L^-T (both from the sweep): one MFMA GEMM that

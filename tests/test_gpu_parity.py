@@ -83,7 +83,7 @@ def test_gemm_is_an_ordered_fmaf_chain():
     g.close()
 
 
-@pytest.mark.parametrize("m,nr", [(2, 25), (64, 30), (130, 100), (512, 790)])
+@pytest.mark.parametrize("m,nr", [(2, 25), (64, 30), (130, 100), (512, 790), (1100, 70)])  # 1100: the split panel/update sweep
 def test_cholesky_and_right_solve(m, nr):
     g = TightlyCoupledEKF(max_features=4)
     rng = np.random.default_rng(m)
