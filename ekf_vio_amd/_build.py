@@ -28,7 +28,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "ekfvio.h")]
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     jobs, objs = [], []
     for src in sources():

@@ -639,7 +639,16 @@ int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[80]) {
     HIPC(f, hipMemcpyAsync(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, f->stream));
     for (int rep = 0; rep < 3; rep++) launch_potrf_stamps(f, dS, 64, dL, dLi, dst);
     HIPC(f, hipMemcpyAsync(stamps, dst, sizeof(long long) * 80, hipMemcpyDeviceToHost, f->stream));
+    std::vector<uint32_t> hl(64 * 64), hi(4096);
+    HIPC(f, hipMemcpyAsync(hl.data(), dL, sizeof(float) * hl.size(), hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipMemcpyAsync(hi.data(), dLi, sizeof(float) * hi.size(), hipMemcpyDeviceToHost, f->stream));
     HIPC(f, hipStreamSynchronize(f->stream));
+    // stamps[12], [13]: FNV-1a hashes of the bits of L and of the 16x16 inverses (variants must agree bit for bit)
+    uint64_t h1 = 1469598103934665603ull, h2 = h1;
+    for (uint32_t v : hl) h1 = (h1 ^ v) * 1099511628211ull;
+    for (uint32_t v : hi) h2 = (h2 ^ v) * 1099511628211ull;
+    stamps[12] = (int64_t)h1;
+    stamps[13] = (int64_t)h2;
     hipFree(dS); hipFree(dL); hipFree(dLi); hipFree(dst);
     return EKFVIO_OK;
 }

@@ -297,14 +297,18 @@ __device__ __forceinline__ void potrf_inverse16(const float* A, float* Tinv, int
     }
 }
 
+#include "potrf_chain.inc"
+
+template <int FV = EKF_POTRF_FV>
 __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long long* stamps = nullptr) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     bool bad = false;
     POTRF_STAMP(1);
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int c0 = 16 * p;
+    static_for<0, 4>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int p = P;
+        constexpr int c0 = 16 * p;
         // ---- phase F ----
         if (wave == 0) {
             float a[16];
@@ -312,18 +316,27 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
             for (int j = 0; j < 16; j++) a[j] = A[(c0 + j) * PLD + lane];
 #pragma unroll
             for (int j = 0; j < 16; j++) asm volatile("" : "+v"(a[j]));  // all LDS reads issue before the chain
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                // a non-positive (or NaN) pivot is clamped so the state stays finite; it leaves
-                // L_kk = 1e-10 behind, which the caller's final diagonal check reports
-                const float d = lane_bcast(fmaxf(a[k], 1e-20f), c0 + k);
-                const float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, <= 1 ulp
-                a[k] *= inv;                                 // lane c0+k: d * inv = L_kk
-#pragma unroll
-                for (int j = k + 1; j < 16; j++) {
-                    const float sj = lane_bcast(a[k], c0 + j);
-                    a[j] = __builtin_fmaf(-a[k], sj, a[j]);
-                }
+            // Column k of the panel: pivot (clamped: a non-positive or NaN pivot leaves L_kk = 1e-10 behind, which the
+            // caller's final diagonal check reports), scale, then a[j] -= a[k] * L[c0+j][c0+k] for the columns j > k.
+            //   FV 8 (production): the generated, hand-scheduled stream of potrf_chain.inc — column k+1 takes its
+            //         multiplier through an SGPR, the others one DPP fma each from a ds_bpermute copy of the diagonal
+            //         block's column, issued in the wait states of the next column's pivot chain;
+            //   FV 0: the plain formulation (every multiplier v_readlane + v_fma), kept as the reference the generated
+            //         stream is checked against: same fma per element in the same order, identical bits
+            //         (scripts/potrf_stamps.py prints hashes of L and the inverses for both).
+            if constexpr (FV == 8) {
+                potrf_panel16_chain<c0>(a, (c0 + (lane & 15)) << 2);
+            } else {
+                static_for<0, 16>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const float d = lane_bcast(fmaxf(a[k], 1e-20f), c0 + k);
+                    const float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, <= 1 ulp
+                    a[k] *= inv;                                 // lane c0+k: d * inv = L_kk
+                    static_for<k + 1, 16>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        a[j] = __builtin_fmaf(-a[k], lane_bcast(a[k], c0 + j), a[j]);
+                    });
+                });
             }
             if (lane >= c0) {
 #pragma unroll
@@ -353,7 +366,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
             __syncthreads();
         }
         POTRF_STAMP(3 + 2 * p);
-    }
+    });
     // the strict upper triangle still holds the symmetric input: store_tile_lower drops it
     if (wave == 0) potrf_inverse16(A, Tinv, 3, lane);
     POTRF_WSTAMP(8);
@@ -364,6 +377,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
 }
 
 // Diagnostic twin of potrf64_kernel: same work, s_memtime stamps after every phase.
+template <int FV>
 __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
                                                             int ldl, float* __restrict__ Linv, long long* stamps) {
     __shared__ float A[PB * PLD];
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restr
     if (tid == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime();
     load_tile(A, S, lds, tid);
     __syncthreads();
-    potrf64_lds(A, Tinv, tid, stamps);
+    potrf64_lds<FV>(A, Tinv, tid, stamps);
     store_tile_lower(A, L, ldl, tid);
     store_inv(Tinv, Linv, tid);
     __syncthreads();
@@ -762,7 +776,10 @@ __global__ __launch_bounds__(256) void chol_sweep_kernel(float* __restrict__ S, 
 }  // namespace
 
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps) {
-    hipLaunchKernelGGL(potrf64_stamp_kernel, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps);
+    const char* e = getenv("EKFVIO_POTRF_FV");  // diagnostic: which factor-phase variant to time
+    const int fv = e ? atoi(e) : EKF_POTRF_FV;
+    auto kern = fv == 0 ? potrf64_stamp_kernel<0> : potrf64_stamp_kernel<8>;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps);
 }
 
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld) {

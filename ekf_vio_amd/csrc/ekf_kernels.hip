@@ -786,7 +786,7 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
 // updateWithFeaturePositions (:475-628) on device-resident z/R/pass; m = 2*(#passed) known to the host
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, int* d_frame_counter,
                    int frames, bool bookkeeping_done) {
-    const int n = f->n, ld = f->ldp, N = f->N;
+    const int n = f->n, ld = f->ldp;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     const int n_pad = round_up(n, EKF_TILE);
     const int lda = f->ld_aug;
