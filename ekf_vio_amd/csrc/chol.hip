@@ -254,7 +254,8 @@ __device__ __forceinline__ void tri_solve_fwd2(float* Tx, float* Ty, const float
 // broadcasts; scaling the pivot column over all 64 lanes IS the panel's triangular solve,
 // so no barrier or LDS round trip sits on the chain.  Schedule per panel p:
 //   phase F: wave 0 factors panel p   ||  waves 1-3 finish the trailing update of panel p-1
-//            (the tiles right of the next panel) and invert diagonal block p-1;
+//            (the tiles right of the next panel); wave 1 inverts diagonal block 0 meanwhile, the
+//            inverses of blocks 1-3 fall out of wave 0's own sweep (identity rows in its dead lanes);
 //   phase C: the tiles that make up panel p+1's columns get panel p's update (<= 3 tiles).
 // Trailing tiles are 16x16 MFMA tiles (v_mfma_f32_16x16x4_f32).
 __device__ __forceinline__ void potrf_tile_update(float* A, int c0, int ti, int tj, int lane) {
@@ -314,6 +315,10 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
             float a[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) a[j] = A[(c0 + j) * PLD + lane];
+            // From the second panel on the first 16 lanes hold rows above the panel (dead values of the symmetric
+            // input).  Waves 1-3 have put the identity there during phase F of panel 0: the column sweep below turns row
+            // i of it into row i of L_pp^-T, i.e. column i of the diagonal block's inverse, for free (the same forward
+            // substitution potrf_inverse16 runs for block 0).
 #pragma unroll
             for (int j = 0; j < 16; j++) asm volatile("" : "+v"(a[j]));  // all LDS reads issue before the chain
             // Column k of the panel: pivot (clamped: a non-positive or NaN pivot leaves L_kk = 1e-10 behind, which the
@@ -342,6 +347,20 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
 #pragma unroll
                 for (int j = 0; j < 16; j++) A[(c0 + j) * PLD + lane] = (lane - c0 >= j) ? a[j] : 0.f;
             }
+            if constexpr (p >= 1) {
+                if (lane < 16) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) Tinv[p * 16 * ILD + lane * ILD + j] = a[j];
+                }
+            }
+        } else if (p == 0) {
+            // identity into the dead blocks (rows 0-15 of the column panels 1-3): 768 entries over 192 threads
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = (tid - 64) + 192 * q;  // 0 .. 767
+                const int c = 16 + (e >> 4), r = e & 15;
+                A[c * PLD + r] = ((c & 15) == r) ? 1.f : 0.f;
+            }
         } else if (p == 1) {
             // rest of panel 0's trailing update: tiles (1,1) | (2,1),(2,2); wave 1 inverts block 0
             if (wave == 1) potrf_inverse16(A, Tinv, 0, lane);
@@ -352,9 +371,6 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
             }
         } else if (p == 2) {
             if (wave == 1) potrf_tile_update(A, 16, 1, 1, lane);
-            if (wave == 2) potrf_inverse16(A, Tinv, 1, lane);
-        } else if (p == 3) {
-            if (wave == 3) potrf_inverse16(A, Tinv, 2, lane);
         }
         POTRF_WSTAMP(2 * p);
         __syncthreads();
@@ -368,9 +384,6 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
         POTRF_STAMP(3 + 2 * p);
     });
     // the strict upper triangle still holds the symmetric input: store_tile_lower drops it
-    if (wave == 0) potrf_inverse16(A, Tinv, 3, lane);
-    POTRF_WSTAMP(8);
-    __syncthreads();
     POTRF_STAMP(10);
     if (wave == 0) bad = __ballot(!(A[lane * PLD + lane] > 2e-10f)) != 0ull;
     return bad;
