@@ -329,6 +329,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
             //   FV 0: the plain formulation (every multiplier v_readlane + v_fma), kept as the reference the generated
             //         stream is checked against: same fma per element in the same order, identical bits
             //         (scripts/potrf_stamps.py prints hashes of L and the inverses for both).
+            if (stamps && p == 0 && lane == 0) stamps[14] = (long long)__builtin_amdgcn_s_memtime();
             if constexpr (FV == 8) {
                 potrf_panel16_chain<c0>(a, (c0 + (lane & 15)) << 2);
             } else {
@@ -343,6 +344,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
                     });
                 });
             }
+            if (stamps && p == 0 && lane == 0) stamps[15] = (long long)__builtin_amdgcn_s_memtime();
             if (lane >= c0) {
 #pragma unroll
                 for (int j = 0; j < 16; j++) A[(c0 + j) * PLD + lane] = (lane - c0 >= j) ? a[j] : 0.f;

@@ -13,6 +13,7 @@ names = ["load", "p0 factor", "p0 trail", "p1 factor", "p1 trail", "p2 factor", 
 # stamps: 0 start,1 after load(+sync) ,2.. 
 for i in range(1, 12):
     print("%-14s %7d ticks" % (names[i - 1], v[i] - v[i - 1]))
+print("panel 0 chain (between the loads and the stores): %d ticks; F0 opened at %d, chain began +%d" % (v[15]-v[14], v[1], v[14]-v[1]))
 print("hash L %016x  inv %016x" % (v[12] & (2**64-1), v[13] & (2**64-1)))
 print("total", v[11] - v[0], "ticks (s_memtime = 100 MHz constant clock? see below)")
 
