@@ -119,6 +119,7 @@ struct ekfvio_filter {
     float* klt_prev_px = nullptr;  // [2*max_features]
     float* klt_next_px = nullptr;  // [2*max_features]
     uint8_t* klt_status = nullptr; // [max_features]
+    float* klt_cov_px = nullptr;   // [4*max_features] sample-based pixel covariances (cfg.sample_based_uncertainty)
     uint8_t* staging = nullptr;    // device staging for the uploaded image
     // --- frame ingest + replenishment (fast.hip) ---
     uint8_t* resized = nullptr;    // Frame::Frame's cv::resize output (max image size)

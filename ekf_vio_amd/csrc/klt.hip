@@ -361,11 +361,102 @@ __global__ void klt_points_kernel(const float* __restrict__ last_klt, const floa
     next_px[2 * i + 1] = fyc * mu[EKF_BASE + 3 * i + 1] + cyc;
 }
 
+// ---- KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) -------------------
+// cv::getRectSubPix(8-bit, Size(5,5), center, CV_32F) (OpenCV 3.x samplers.cpp, getRectSubPix_8u32f): one patch row.
+// Inside the image the horizontal interpolation is carried from pixel to pixel through a double factor
+// (prev = (float)(t * s), s = (1 - a) / a); at the border: replicate-clamped bilinear taps.  `img` points at pixel
+// (0,0) of level 0 (the pyramid's reflect-101 border is not what getRectSubPix sees, so coordinates are clamped).
+__device__ __forceinline__ void rect_subpix5_row(const uint8_t* __restrict__ img, int pitch, int w, int h, float cx, float cy, int i,
+                                                 float out[5]) {
+    cx -= 2.0f;
+    cy -= 2.0f;
+    const int ipx = (int)floorf(cx), ipy = (int)floorf(cy);
+    if (0 <= ipx && ipx + 5 < w && 0 <= ipy && ipy + 5 < h) {
+        float a = cx - (float)ipx;
+        const float b = cy - (float)ipy;
+        a = fmaxf(a, 0.0001f);
+        const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+        const double sc = (1. - (double)a) / (double)a;
+        const uint8_t* src = img + (size_t)(ipy + i) * pitch + ipx;
+        float prev = (1 - a) * (b1 * (float)src[0] + b2 * (float)src[pitch]);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const float t = a12 * (float)src[j + 1] + a22 * (float)src[j + 1 + pitch];
+            out[j] = prev + t;
+            prev = (float)((double)t * sc);
+        }
+    } else {
+        const float a = cx - (float)ipx, b = cy - (float)ipy;
+        const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+        const int y0 = min(max(ipy + i, 0), h - 1), y1 = min(max(ipy + i + 1, 0), h - 1);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int x0 = min(max(ipx + j, 0), w - 1), x1 = min(max(ipx + j + 1, 0), w - 1);
+            out[j] = (float)img[(size_t)y0 * pitch + x0] * a11 + (float)img[(size_t)y0 * pitch + x1] * a12 +
+                     (float)img[(size_t)y1 * pitch + x0] * a21 + (float)img[(size_t)y1 * pitch + x1] * a22;
+        }
+    }
+}
+
+// 32 threads per point, two points per 64-thread block.  Threads 0-4 of a group form the reference patch (one row
+// each) in LDS; threads 0-24 then own one of the 25 samples (du = 5*(s/5) - 10 outer, dv = 5*(s%5) - 10 inner), form
+// its patch row by row and accumulate the squared differences in the reference's (i, j) order: pow(float, 2) and
+// exp(float) promote to double there, the sums are float; thread 0 adds the 25 weighted samples in loop order.
+__global__ __launch_bounds__(64) void klt_uncertainty_kernel(const uint8_t* __restrict__ prev, int ppitch, int pw, int ph,
+                                                             const uint8_t* __restrict__ cur, int cpitch, int cw, int ch,
+                                                             const float* __restrict__ ref_px, const float* __restrict__ cur_px,
+                                                             int n, float* __restrict__ cov) {
+    __shared__ float ref[2][25];
+    __shared__ float rd_s[2][25];
+    const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
+    const int pt = blockIdx.x * 2 + g;
+    const bool live = pt < n;
+    if (live && t < 5) {
+        float row[5];
+        rect_subpix5_row(prev, ppitch, pw, ph, ref_px[2 * pt], ref_px[2 * pt + 1], t, row);
+#pragma unroll
+        for (int j = 0; j < 5; j++) ref[g][t * 5 + j] = row[j];
+    }
+    __syncthreads();
+    if (live && t < 25) {
+        const float du = (float)(5 * (t / 5) - 10), dv = (float)(5 * (t % 5) - 10);
+        const float sx = cur_px[2 * pt] + du, sy = cur_px[2 * pt + 1] + dv;
+        float ssd = 0.f;
+        for (int i = 0; i < 5; i++) {
+            float row[5];
+            rect_subpix5_row(cur, cpitch, cw, ch, sx, sy, i, row);
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const double d = (double)(ref[g][i * 5 + j] - row[j]);
+                ssd = (float)((double)ssd + d * d);
+            }
+        }
+        ssd /= 25.f;
+        rd_s[g][t] = (float)exp((double)(-0.01f * ssd));
+    }
+    __syncthreads();
+    if (live && t == 0) {
+        float sum_rd = 0.f, sum_xx = 0.f, sum_yy = 0.f, sum_xy = 0.f;
+        for (int s = 0; s < 25; s++) {
+            const float du = (float)(5 * (s / 5) - 10), dv = (float)(5 * (s % 5) - 10);
+            const float rd = rd_s[g][s];
+            sum_rd += rd;
+            sum_xx += rd * du * du;
+            sum_yy += rd * dv * dv;
+            sum_xy += rd * du * dv;
+        }
+        cov[4 * pt] = sum_xx / sum_rd;
+        cov[4 * pt + 1] = sum_xy / sum_rd;
+        cov[4 * pt + 2] = sum_xy / sum_rd;
+        cov[4 * pt + 3] = sum_yy / sum_rd;
+    }
+}
+
 // KLTTracker.cpp:72-92: pass = status && inside the kill pad; z = pixel2Metric; R = 1e-5 I px^2
 // scaled by (1/fx)^2 on row 0 and (1/fy)^2 on row 1.
 __global__ void klt_finish_kernel(const float* __restrict__ next_px, const uint8_t* __restrict__ status, int N, int w,
-                                  int h, int kill_pad, float fx, float fy, float cx, float cy, float r0, float r1, float* z,
-                                  float* R, uint8_t* pass) {
+                                  int h, int kill_pad, float fx, float fy, float cx, float cy, float r0, float r1,
+                                  const float* __restrict__ cov_px, float s0, float s1, float* z, float* R, uint8_t* pass) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float x = next_px[2 * i], y = next_px[2 * i + 1];
@@ -374,10 +465,18 @@ __global__ void klt_finish_kernel(const float* __restrict__ next_px, const uint8
     if (p) {
         z[2 * i] = (x - cx) / fx;
         z[2 * i + 1] = (y - cy) / fy;
-        R[4 * i] = r0;
-        R[4 * i + 1] = 0.f;  // the off-diagonals of estimateUncertainty are zero, scaled or not
-        R[4 * i + 2] = 0.f;
-        R[4 * i + 3] = r1;
+        if (cov_px) {  // estimateUncertaintySampleBased's matrix through the same conversion (:79-84): row 0 by
+                       // (1/fx)^2, row 1 by (1/fy)^2
+            R[4 * i] = cov_px[4 * i] * s0;
+            R[4 * i + 1] = cov_px[4 * i + 1] * s0;
+            R[4 * i + 2] = cov_px[4 * i + 2] * s1;
+            R[4 * i + 3] = cov_px[4 * i + 3] * s1;
+        } else {
+            R[4 * i] = r0;
+            R[4 * i + 1] = 0.f;  // the off-diagonals of estimateUncertainty are zero, scaled or not
+            R[4 * i + 2] = 0.f;
+            R[4 * i + 3] = r1;
+        }
     } else {
         z[2 * i] = 0.f;
         z[2 * i + 1] = 0.f;
@@ -430,6 +529,7 @@ int klt_alloc(ekfvio_filter* f) {
     HIPK(f, hipMalloc((void**)&f->klt_prev_px, sizeof(float) * 2 * maxf));
     HIPK(f, hipMalloc((void**)&f->klt_next_px, sizeof(float) * 2 * maxf));
     HIPK(f, hipMalloc((void**)&f->klt_status, maxf));
+    HIPK(f, hipMalloc((void**)&f->klt_cov_px, sizeof(float) * 4 * maxf));
     HIPK(f, hipMalloc((void**)&f->staging, (size_t)c.max_image_width * c.max_image_height));
     return EKFVIO_OK;
 }
@@ -443,6 +543,7 @@ void klt_free(ekfvio_filter* f) {
     if (f->klt_prev_px) (void)hipFree(f->klt_prev_px);
     if (f->klt_next_px) (void)hipFree(f->klt_next_px);
     if (f->klt_status) (void)hipFree(f->klt_status);
+    if (f->klt_cov_px) (void)hipFree(f->klt_cov_px);
     if (f->staging) (void)hipFree(f->staging);
 }
 
@@ -497,6 +598,17 @@ static int track_points_device(ekfvio_filter* f, int n) {
     return EKFVIO_OK;
 }
 
+// Pixel covariances of the n points in f->klt_prev_px (previous frame) / f->klt_next_px (current frame) -> f->klt_cov_px.
+static void uncertainty_device(ekfvio_filter* f, int n) {
+    const KltFrame& prev = f->frames[f->cur ^ 1];
+    const KltFrame& cur = f->frames[f->cur];
+    const int pp = level_pitch(prev.w[0]), cp = level_pitch(cur.w[0]);
+    hipLaunchKernelGGL(klt_uncertainty_kernel, dim3((n + 1) / 2), dim3(64), 0, f->stream,
+                       prev.img[0] + (size_t)KLT_BORDER * pp + KLT_BORDER, pp, prev.w[0], prev.h[0],
+                       cur.img[0] + (size_t)KLT_BORDER * cp + KLT_BORDER, cp, cur.w[0], cur.h[0], f->klt_prev_px, f->klt_next_px, n,
+                       f->klt_cov_px);
+}
+
 // Runs the tracker for the current landmarks; results land in f->zmeas / Rmeas / pass (device).
 int klt_track_device(ekfvio_filter* f) {
     const KltFrame& prev = f->frames[f->cur ^ 1];
@@ -516,8 +628,15 @@ int klt_track_device(ekfvio_filter* f) {
     // estimateUncertainty (:100-106) = 1e-5 I; scale = pow(1.0/K(0,0), 2) in double, narrowed
     const float r0 = 0.00001f * (float)pow(1.0 / (double)cur.K[0], 2);
     const float r1 = 0.00001f * (float)pow(1.0 / (double)cur.K[4], 2);
+    const float s0 = (float)pow(1.0 / (double)cur.K[0], 2), s1 = (float)pow(1.0 / (double)cur.K[4], 2);
+    const float* cov_px = nullptr;
+    if (f->cfg.sample_based_uncertainty) {  // estimateUncertaintySampleBased(lf, prev_fts[i], cf, new_fts[i])
+        uncertainty_device(f, N);
+        cov_px = f->klt_cov_px;
+    }
     hipLaunchKernelGGL(klt_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->klt_next_px, f->klt_status, N,
-                       cur.w[0], cur.h[0], f->cfg.kill_pad, fxc, fyc, cxc, cyc, r0, r1, f->zmeas, f->Rmeas, f->pass);
+                       cur.w[0], cur.h[0], f->cfg.kill_pad, fxc, fyc, cxc, cyc, r0, r1, cov_px, s0, s1, f->zmeas, f->Rmeas,
+                       f->pass);
     return EKFVIO_OK;
 }
 
@@ -581,6 +700,24 @@ int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float*
     track_points_device(f, count);
     if (out_px) HIPK(f, hipMemcpyAsync(out_px, f->klt_next_px, sizeof(float) * 2 * count, hipMemcpyDeviceToHost, f->stream));
     if (status) HIPK(f, hipMemcpyAsync(status, f->klt_status, count, hipMemcpyDeviceToHost, f->stream));
+    HIPK(f, hipGetLastError());
+    HIPK(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_klt_uncertainty_points(ekfvio_filter* f, const float* ref_px, const float* cur_px, int32_t count, float* cov4) {
+    if (!f || !ref_px || !cur_px || !cov4 || count < 0) return EKFVIO_EINVAL;
+    if (count > f->cfg.max_features) return EKFVIO_ECAPACITY;
+    if (!f->frames[0].valid || !f->frames[1].valid) {
+        f->last_error = "the sample-based uncertainty needs two frames";
+        return EKFVIO_ESTATE;
+    }
+    if (count == 0) return EKFVIO_OK;
+    HIPK(f, hipSetDevice(f->device));
+    HIPK(f, hipMemcpyAsync(f->klt_prev_px, ref_px, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    HIPK(f, hipMemcpyAsync(f->klt_next_px, cur_px, sizeof(float) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    uncertainty_device(f, count);
+    HIPK(f, hipMemcpyAsync(cov4, f->klt_cov_px, sizeof(float) * 4 * count, hipMemcpyDeviceToHost, f->stream));
     HIPK(f, hipGetLastError());
     HIPK(f, hipStreamSynchronize(f->stream));
     return EKFVIO_OK;

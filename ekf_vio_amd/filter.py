@@ -249,6 +249,15 @@ class KLTTracker:
         self.ekf._chk(self.lib.ekfvio_klt_track_points(self.ekf.h, _fp(pp), _fp(ii), pp.shape[0], _fp(out), _u8(st)))
         return out, st
 
+    def uncertainty_points(self, ref_px, cur_px):
+        """KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) for arbitrary points between the two
+        resident frames: cov[n, 2, 2] in px^2."""
+        rp = np.ascontiguousarray(ref_px, dtype=np.float32).reshape(-1, 2)
+        cp = np.ascontiguousarray(cur_px, dtype=np.float32).reshape(-1, 2)
+        cov = np.zeros((rp.shape[0], 4), np.float32)
+        self.ekf._chk(self.lib.ekfvio_klt_uncertainty_points(self.ekf.h, _fp(rp), _fp(cp), rp.shape[0], _fp(cov)))
+        return cov.reshape(-1, 2, 2)
+
     def level(self, l):
         w, h = C.c_int32(0), C.c_int32(0)
         self.ekf._chk(self.lib.ekfvio_klt_get_level(self.ekf.h, l, C.byref(w), C.byref(h), None, None))

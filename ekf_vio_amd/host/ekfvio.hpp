@@ -152,6 +152,16 @@ class KLTTracker {
                                   N ? estimated_uncertainty[0].data() : nullptr, passed.data()));
     }
 
+    // KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) for n points between the two frames pushed
+    // last: pixel-space covariances (px^2).  mu_ref in the previous frame, mu in the current one.
+    void estimateUncertaintySampleBased(const std::vector<Vector2f>& mu_ref, const std::vector<Vector2f>& mu,
+                                        std::vector<Matrix2f>& cov) {
+        if (mu_ref.size() != mu.size()) throw Error(EKFVIO_EINVAL, "estimateUncertaintySampleBased: size mismatch");
+        cov.resize(mu.size());
+        if (mu.empty()) return;
+        ekf_.chk(ekfvio_klt_uncertainty_points(ekf_.handle(), mu_ref[0].data(), mu[0].data(), (int32_t)mu.size(), cov[0].data()));
+    }
+
    private:
     TightlyCoupledEKF& ekf_;
 };

@@ -68,6 +68,8 @@ typedef struct ekfvio_config {
     int32_t min_new_feature_dist;          /* MIN_NEW_FEATURE_DIST 30 (radius of the occupancy circles) */
     float fast_blur_sigma;                 /* FAST_BLUR_SIGMA 0 = off; non-zero is rejected (not implemented) */
     int32_t replenish;                     /* 1: ekfvio_step_image also runs replenishFeatures */
+    int32_t sample_based_uncertainty;      /* 0 (reference behaviour): R = 1e-5 I px^2 (estimateUncertainty, KLTTracker.cpp:100-106);
+                                              1: R from estimateUncertaintySampleBased (:111-175, dead code there) */
 } ekfvio_config;
 
 /* Fills `cfg` with the reference defaults (Params.h D_* values). */
@@ -133,6 +135,12 @@ int ekfvio_klt_track(ekfvio_filter* f, float* z2N, float* R4N, uint8_t* passN);
  * OPTFLOW_USE_INITIAL_FLOW) between the two resident frames; for tests. */
 int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float* init_px, int32_t count,
                             float* out_px, uint8_t* status);
+
+/* KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) between the two resident frames: for every
+ * point a pixel-space 2x2 covariance (row-major, px^2) from 25 samples (offsets -10..10 step 5 around cur_px) of 5x5
+ * sub-pixel patches (cv::getRectSubPix semantics) weighted by exp(-0.01 * mean squared difference to the 5x5
+ * reference patch at ref_px in the previous frame).  Host pointers. */
+int ekfvio_klt_uncertainty_points(ekfvio_filter* f, const float* ref_px, const float* cur_px, int32_t count, float* cov4);
 
 /* Test hook: interior of pyramid level `level` of the current frame (8-bit image, w*h, and
  * interleaved int16 Scharr dx,dy, w*h*2).  Either output may be NULL. */

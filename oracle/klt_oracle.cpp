@@ -270,4 +270,86 @@ void orc_klt_track(void* prev_p, void* next_p, const float* prev_px, float* next
     }
 }
 
+// ---- KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) -------------------
+// Dead code in the reference (estimateUncertainty, :100-106, returns the constant 1e-5 I instead); restated so that
+// the optional sample-based measurement covariance of the HIP path has a checker.
+//
+// cv::getRectSubPix(8-bit image, Size(5,5), center, patch, CV_32F) as published in OpenCV 3.x
+// modules/imgproc/src/samplers.cpp (getRectSubPix_8u32f): the patch's top-left sample sits at
+// center - (win-1)/2; ip = floor, a, b the fractions, a = max(a, 1e-4f).  Window strictly inside the image: per row
+//     prev = (1-a) * (b1*src[0] + b2*src[step]);  for j: t = a12*src[j+1] + a22*src[j+1+step]; dst[j] = prev + t;
+//     prev = (float)(t * s)   with   double s = (1 - a) / a
+// (the horizontal interpolation is carried from pixel to pixel).  Otherwise: border-replicated bilinear taps with
+// weights a11 = (1-a)(1-b), a12 = a(1-b), a21 = (1-a)b, a22 = ab — equal to OpenCV's adjustRect path in exact
+// arithmetic; its summation order there is not restated ("parity unpinned", OpenCV absent and unpinned).
+static void rect_subpix5(const uint8_t* img, int w, int h, int stride, float cx, float cy, float* dst /* 5x5 row-major */) {
+    const int win = 5;
+    cx -= (win - 1) * 0.5f;
+    cy -= (win - 1) * 0.5f;
+    const int ipx = cv_floor(cx), ipy = cv_floor(cy);
+    if (0 <= ipx && ipx + win < w && 0 <= ipy && ipy + win < h) {
+        float a = cx - ipx;
+        const float b = cy - ipy;
+        a = a > 0.0001f ? a : 0.0001f;
+        const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+        const double sc = (1. - a) / a;
+        const uint8_t* src = img + (size_t)ipy * stride + ipx;
+        for (int i = 0; i < win; i++, src += stride) {
+            float prev = (1 - a) * (b1 * src[0] + b2 * src[stride]);
+            for (int j = 0; j < win; j++) {
+                const float t = a12 * src[j + 1] + a22 * src[j + 1 + stride];
+                dst[i * win + j] = prev + t;
+                prev = (float)(t * sc);
+            }
+        }
+    } else {
+        const float a = cx - ipx, b = cy - ipy;
+        const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+        auto px = [&](int x, int y) -> float {
+            x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+            y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+            return (float)img[(size_t)y * stride + x];
+        };
+        for (int i = 0; i < win; i++)
+            for (int j = 0; j < win; j++)
+                dst[i * win + j] = px(ipx + j, ipy + i) * a11 + px(ipx + j + 1, ipy + i) * a12 + px(ipx + j, ipy + i + 1) * a21 +
+                                   px(ipx + j + 1, ipy + i + 1) * a22;
+    }
+}
+
+// ref_px / cur_px: n x 2 pixel positions in the previous / current level-0 image; cov: n x 4 (row-major 2x2, px^2).
+// Arithmetic as written at :127-166: pow(float, 2) and exp(float) promote to double, the sums are float, samples run
+// du outer / dv inner over {-10,-5,0,5,10}.
+void orc_klt_uncertainty(void* prev_p, void* cur_p, const float* ref_px, const float* cur_px, int n, float* cov) {
+    const Level& P = ((Frame*)prev_p)->lv[0];
+    const Level& Cc = ((Frame*)cur_p)->lv[0];
+    for (int t = 0; t < n; t++) {
+        float ref[25], smp[25];
+        rect_subpix5(P.img.data(), P.w, P.h, P.w, ref_px[2 * t], ref_px[2 * t + 1], ref);
+        const float window_area = 25.f, k = 0.01f;
+        float sum_rd = 0, sum_xx = 0, sum_yy = 0, sum_xy = 0;
+        for (float du = -10; du <= 10; du += 5) {
+            for (float dv = -10; dv <= 10; dv += 5) {
+                rect_subpix5(Cc.img.data(), Cc.w, Cc.h, Cc.w, cur_px[2 * t] + du, cur_px[2 * t + 1] + dv, smp);
+                float ssd = 0;
+                for (int i = 0; i < 5; i++)
+                    for (int j = 0; j < 5; j++) {
+                        const double d = (double)(ref[i * 5 + j] - smp[i * 5 + j]);
+                        ssd = (float)((double)ssd + d * d);
+                    }
+                ssd /= window_area;
+                const float rd = (float)std::exp((double)(-k * ssd));
+                sum_rd += rd;
+                sum_xx += rd * du * du;
+                sum_yy += rd * dv * dv;
+                sum_xy += rd * du * dv;
+            }
+        }
+        cov[4 * t + 0] = sum_xx / sum_rd;
+        cov[4 * t + 3] = sum_yy / sum_rd;
+        cov[4 * t + 1] = sum_xy / sum_rd;
+        cov[4 * t + 2] = cov[4 * t + 1];
+    }
+}
+
 }  // extern "C"

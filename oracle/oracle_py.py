@@ -68,6 +68,7 @@ def _declare(lib):
     lib.orc_klt_level_size.argtypes = [vp, i32, ip, ip]
     lib.orc_klt_get_level.argtypes = [vp, i32, u8p, i16p]
     lib.orc_klt_track.argtypes = [vp, vp, fpp, fpp, i32, i32, i32, C.c_float, C.c_float, i32, u8p, ip]
+    lib.orc_klt_uncertainty.argtypes = [vp, vp, fpp, fpp, i32, fpp]
     lib.orc_set_threads.argtypes = [i32]
     lib.orc_max_threads.restype = i32
     lib.orc_frame_resize.argtypes = [u8p, i32, i32, i32, i32, u8p]
@@ -245,6 +246,18 @@ def klt_track(prev, nxt, prev_px, init_px, win=21, max_iter=30, epsilon=0.01, mi
     lib.orc_klt_track(prev.p, nxt.p, _p(pp, C.c_float), _p(nn, C.c_float), n, win, max_iter, epsilon, min_eig,
                       accum_mode, _p(st, C.c_uint8), it.ctypes.data_as(C.POINTER(C.c_int)))
     return nn, st, it
+
+
+def klt_uncertainty(prev, cur, ref_px, cur_px):
+    """KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) restated: pixel-space 2x2 covariance per
+    point from 25 SSD-weighted samples of 5x5 sub-pixel patches.  Returns cov[n,2,2] float32."""
+    lib = oracle_lib()
+    rp = np.ascontiguousarray(ref_px, dtype=np.float32).reshape(-1, 2)
+    cp = np.ascontiguousarray(cur_px, dtype=np.float32).reshape(-1, 2)
+    n = rp.shape[0]
+    cov = np.zeros((n, 4), np.float32)
+    lib.orc_klt_uncertainty(prev.p, cur.p, _p(rp, C.c_float), _p(cp, C.c_float), n, _p(cov, C.c_float))
+    return cov.reshape(n, 2, 2)
 
 
 # ---- frame ingest and landmark replenishment (fast_oracle.cpp; SURVEY 8(f) F1/F2) ----

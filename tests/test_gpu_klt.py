@@ -9,7 +9,7 @@ import pytest
 from PIL import Image
 
 from ekf_vio_amd import EKFVIO, KLTTracker, TightlyCoupledEKF, capi, EkfvioError
-from oracle import KltFrame, OracleFilter, klt_track
+from oracle import KltFrame, OracleFilter, klt_track, klt_uncertainty
 
 from _scatter import backward_yardstick
 
@@ -147,3 +147,65 @@ def test_config1_klt_plus_64_landmark_update():
     assert od["position"].shape == (3,) and abs(np.linalg.norm(od["orientation_wxyz"]) - 1) < 1e-6
     assert v.points().shape == (64, 3)
     v.tc_ekf.close()
+
+
+def test_sample_based_uncertainty_matches_oracle():
+    """SURVEY 8(f) F4: KLTTracker::estimateUncertaintySampleBased (dead code in the reference) as a HIP kernel.  The
+    kernel repeats the oracle's scalar arithmetic (getRectSubPix recurrence, double pow, float sums in loop order);
+    only exp() comes from a different libm, so the covariances agree to a few float ulps.  Points cover the image
+    interior, the replicate border, positions outside the image and the symmetric-sample case (same frame twice)."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    g = TightlyCoupledEKF(max_features=256)
+    t = KLTTracker(g)
+    t.push_frame(a, K), t.push_frame(b, K)
+    ref = np.vstack([grid_points(8), grid_points(12)[:100] + np.float32(0.37),
+                     [[1.0, 1.0], [638.5, 478.5], [3.99, 240.0], [320.0, 2.0], [-30.0, 50.0], [700.0, 500.0]]]).astype(np.float32)
+    cur = ref + np.array([-21.0, -7.0], np.float32)
+    A, B = KltFrame(a), KltFrame(b)
+    oc = klt_uncertainty(A, B, ref, cur)
+    gc = t.uncertainty_points(ref, cur)
+    assert np.isfinite(gc).all()
+    assert np.allclose(gc, oc, rtol=2e-6, atol=1e-6), float(np.abs(gc - oc).max())
+    assert np.array_equal(gc[:, 0, 1], gc[:, 1, 0])
+    # a well-textured, correctly tracked point is far more certain than the +-10 px sample spread of a flat one
+    assert np.median(gc[:64, 0, 0]) < 50.0 and (gc[:, 0, 0] >= 0).all() and (gc[:, 1, 1] >= 0).all()
+    # same frame twice, reference == sample centre: the weights are symmetric in du and dv only if the image is;
+    # what must hold exactly is the centre sample's weight exp(0) = 1 bounding the sum from below
+    t.push_frame(b, K)
+    same = t.uncertainty_points(ref[:64], ref[:64])
+    assert np.allclose(same, klt_uncertainty(B, B, ref[:64], ref[:64]), rtol=2e-6, atol=1e-6)
+    g.close()
+
+
+def test_sample_based_uncertainty_feeds_the_update_behind_its_flag():
+    """cfg.sample_based_uncertainty = 1: ekfvio_klt_track hands the filter R = the sample covariance through the
+    reference's pixel->metric conversion (KLTTracker.cpp:79-84: row 0 by (1/fx)^2, row 1 by (1/fy)^2); default 0
+    keeps estimateUncertainty's constant."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    px = grid_points(8)
+    uv = _metric(px)
+    out = {}
+    for flag in (0, 1):
+        g = TightlyCoupledEKF(max_features=64, sample_based_uncertainty=flag)
+        t = KLTTracker(g)
+        t.push_frame(a, K)
+        g.addNewFeatures(uv)
+        t.push_frame(b, K)
+        z, R, p = t.findNewFeaturePositions()
+        out[flag] = (z, R.reshape(-1, 4), p)
+        if flag:
+            st = g.get_state()
+            prev_px = np.stack([st["last_klt"][:, 0] * K[0], st["last_klt"][:, 1] * K[4]], axis=1).astype(np.float32)
+            nxt = np.stack([z.reshape(-1, 2)[:, 0] * K[0], z.reshape(-1, 2)[:, 1] * K[4]], axis=1).astype(np.float32)
+            cov = t.uncertainty_points(prev_px, nxt).reshape(-1, 4)
+        g.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    ok = out[1][2] == 1
+    assert ok.sum() >= 60
+    s0 = np.float32((1.0 / np.float64(K[0])) ** 2)
+    s1 = np.float32((1.0 / np.float64(K[4])) ** 2)
+    want = cov * np.array([s0, s0, s1, s1], np.float32)
+    # z is metric = (px - 0) / fx: going back to pixels rounds, so the comparison is to float tolerance, not bits
+    assert np.allclose(out[1][1][ok], want[ok], rtol=1e-3, atol=1e-9)
+    assert np.allclose(out[0][1][ok][:, 0], np.float32(1e-5) * s0) and (out[0][1][ok][:, 1] == 0).all()
+    assert (out[1][1][~ok] == 0).all()

@@ -88,3 +88,26 @@ def test_integer_and_float_accumulation_agree():
     n1, s1, _ = klt_track(A, B, pts, pts.copy(), accum_mode=1)
     both = (s0 == 1) & (s1 == 1)
     assert (s0 != s1).sum() <= 1 and np.abs(n0 - n1)[both].max() < 0.02
+
+
+def test_sample_based_uncertainty_known_answers():
+    """estimateUncertaintySampleBased restated (KLTTracker.cpp:111-175).  Known answers that follow from the text of
+    the function alone: on a constant image every sample matches (ssd = 0, weight exp(0) = 1), so the covariance is
+    the second moment of the 5x5 sample grid {-10,-5,0,5,10}^2: diag(50, 50) exactly; a strong isolated blob makes
+    the centre sample dominate (covariance -> 0); and on an image that varies along x only, the samples along y all
+    match, which leaves the y variance at 50 and shrinks the x variance."""
+    from oracle import klt_uncertainty
+    flat = np.full((80, 100), 77, np.uint8)
+    F = KltFrame(flat)
+    pts = np.array([[50.0, 40.0], [20.25, 30.75], [2.0, 2.0], [99.0, 79.0]], np.float32)
+    c = klt_uncertainty(F, F, pts, pts)
+    assert np.array_equal(c, np.tile(np.array([[50.0, 0.0], [0.0, 50.0]], np.float32), (4, 1, 1)))
+    yy, xx = np.mgrid[0:80, 0:100]
+    blob = (255.0 * np.exp(-((xx - 50) ** 2 + (yy - 40) ** 2) / 8.0)).astype(np.uint8)
+    Bf = KltFrame(blob)
+    cb = klt_uncertainty(Bf, Bf, [[50.0, 40.0]], [[50.0, 40.0]])[0]
+    assert cb[0, 0] < 1e-3 and cb[1, 1] < 1e-3 and cb[0, 1] == cb[1, 0]
+    ramp = np.tile((np.arange(100) * 2.5).astype(np.uint8), (80, 1))
+    Rf = KltFrame(ramp)
+    cr = klt_uncertainty(Rf, Rf, [[50.5, 40.0]], [[50.5, 40.0]])[0]
+    assert abs(cr[1, 1] - 50.0) < 1e-4 and cr[0, 0] < 30.0 and abs(cr[0, 1]) < 1e-4
