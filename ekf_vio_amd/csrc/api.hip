@@ -104,7 +104,7 @@ int ekfvio_default_config(ekfvio_config* c) {
     c->inverse_image_scale = 1;   // D_INVERSE_IMAGE_SCALE is 4; 1 = the caller hands over frames already at working size
     c->fast_threshold = 50;       // D_FAST_THRESHOLD
     c->min_new_feature_dist = 30; // D_MIN_NEW_FEATURE_DIST
-    c->fast_blur_sigma = 0.f;     // D_FAST_BLUR_SIGMA (0 = no blur; other values are not implemented)
+    c->fast_blur_sigma = 0.f;     // D_FAST_BLUR_SIGMA (0 = no blur)
     c->replenish = 0;             // 1: ekfvio_step_image runs replenishFeatures (EKFVIO.cpp:154,172) itself
     c->sample_based_uncertainty = 0;  // reference behaviour: estimateUncertainty's constant (KLTTracker.cpp:100-106)
     return EKFVIO_OK;

@@ -123,6 +123,7 @@ struct ekfvio_filter {
     uint8_t* staging = nullptr;    // device staging for the uploaded image
     // --- frame ingest + replenishment (fast.hip) ---
     uint8_t* resized = nullptr;    // Frame::Frame's cv::resize output (max image size)
+    uint8_t* blurred = nullptr;    // replenishFeatures' cv::GaussianBlur output (only with cfg.fast_blur_sigma != 0)
     short* fast_score = nullptr;   // FAST score map of level 0 (-1 = no corner)
     int* fast_kp_xy = nullptr;     // keypoints in raster order
     short* fast_kp_score = nullptr;

@@ -333,12 +333,59 @@ __global__ __launch_bounds__(64) void replenish_select_kernel(const int* __restr
     if (lane == 0) *new_count = added;
 }
 
+// cv::GaussianBlur(img, Size(5,5), sigma) on level 0 (EKFVIO.cpp:228-232, FAST_BLUR_SIGMA != 0): OpenCV 3.x runs
+// symmetric smoothing kernels on 8-bit data in fixed point (taps k = round(256 * g), exact integer row and column
+// sums, (v + 2^15) >> 16), so the separable filter equals this single 25-tap integer sum.  `img` is level 0 inside its
+// reflect-101 border (>= 2 pixels: BORDER_DEFAULT needs no special case); four outputs per thread.
+__global__ __launch_bounds__(256) void gauss5_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h, int k0, int k1, int k2,
+                                                     uint8_t* __restrict__ out) {
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= w) return;
+    const int kk[5] = {k0, k1, k2, k1, k0};
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint8_t* r = img + (ptrdiff_t)(y + i - 2) * pitch + x0 - 2;
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = r[j];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            int rs = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) rs += kk[j] * v[o + j];
+            acc[o] += kk[i] * rs;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+        if (x0 + o < w) out[(size_t)y * w + x0 + o] = (uint8_t)min(max((acc[o] + (1 << 15)) >> 16, 0), 255);
+}
+
 }  // namespace
+
+// getGaussianKernel(5, sigma, CV_32F) (smooth.cpp) -> the fixed-point taps of createSeparableLinearFilter's 8-bit path
+static void gauss5_taps(float sigma, int k[5]) {
+    float cf[5];
+    const double scale2x = -0.5 / ((double)sigma * (double)sigma);
+    double sum = 0;
+    for (int i = 0; i < 5; i++) {
+        const double x = i - 2.0;
+        cf[i] = (float)std::exp(scale2x * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 5; i++) {
+        cf[i] = (float)(cf[i] * sum);
+        k[i] = (int)std::nearbyint((double)(cf[i] * 256.f));  // cvRound: half to even
+    }
+}
 
 int fast_alloc(ekfvio_filter* f) {
     const ekfvio_config& c = f->cfg;
     const size_t px = (size_t)c.max_image_width * c.max_image_height;
     HIPF(f, hipMalloc((void**)&f->resized, px));
+    if (c.fast_blur_sigma != 0.f) HIPF(f, hipMalloc((void**)&f->blurred, px));
     HIPF(f, hipMalloc((void**)&f->fast_score, px * sizeof(short)));
     f->fast_kp_cap = (int)(px / 4 + 1);
     HIPF(f, hipMalloc((void**)&f->fast_kp_xy, (size_t)f->fast_kp_cap * 2 * sizeof(int)));
@@ -353,7 +400,7 @@ int fast_alloc(ekfvio_filter* f) {
 }
 
 void fast_free(ekfvio_filter* f) {
-    void* ptrs[] = {f->resized, f->fast_score, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt, f->fast_row_off};
+    void* ptrs[] = {f->resized, f->blurred, f->fast_score, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt, f->fast_row_off};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -366,14 +413,23 @@ void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale) {
 }
 
 // cv::FAST on level 0 of the current frame -> f->fast_kp_* (raster order), count in f->fast_counts[0]
-int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax) {
+int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur) {
     const KltFrame& fr = f->frames[f->cur];
     if (!fr.valid) {
         f->last_error = "FAST needs a frame";
         return EKFVIO_ESTATE;
     }
-    const int w = fr.w[0], h = fr.h[0], pitch = klt_level_pitch(w);
+    const int w = fr.w[0], h = fr.h[0];
+    int pitch = klt_level_pitch(w);
     const uint8_t* img0 = fr.img[0] + (size_t)klt_border() * pitch + klt_border();
+    if (blur) {  // replenishFeatures: cv::GaussianBlur(f.img, img, Size(5,5), FAST_BLUR_SIGMA) (EKFVIO.cpp:228-232)
+        int k[5];
+        gauss5_taps(f->cfg.fast_blur_sigma, k);
+        hipLaunchKernelGGL(gauss5_kernel, dim3((w + 1023) / 1024, h), dim3(256), 0, f->stream, img0, pitch, w, h, k[0], k[1], k[2],
+                           f->blurred);
+        img0 = f->blurred;
+        pitch = w;
+    }
     hipLaunchKernelGGL(fast_score_kernel, dim3((w + 255) / 256, h), dim3(256), 0, f->stream, img0, w, h, pitch, threshold, f->fast_score);
     hipLaunchKernelGGL(fast_row_count_kernel, dim3(h), dim3(256), 0, f->stream, f->fast_score, w, h, nonmax, f->fast_row_cnt);
     hipLaunchKernelGGL(fast_row_scan_kernel, dim3(1), dim3(1024), 0, f->stream, f->fast_row_cnt, h, f->fast_row_off, f->fast_counts);
@@ -387,7 +443,7 @@ extern "C" {
 int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score, int32_t* count) {
     if (!f || !count || cap < 0) return EKFVIO_EINVAL;
     HIPF(f, hipSetDevice(f->device));
-    int rc = fast_detect_device(f, threshold, nonmax);
+    int rc = fast_detect_device(f, threshold, nonmax, f->cfg.fast_blur_sigma != 0.f);
     if (rc != EKFVIO_OK) return rc;
     int n = 0;
     HIPF(f, hipMemcpyAsync(&n, f->fast_counts, sizeof(int), hipMemcpyDeviceToHost, f->stream));
@@ -405,11 +461,22 @@ int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int3
     return EKFVIO_OK;
 }
 
+// Test hook: the Gaussian-blurred level 0 the last FAST run saw (w*h bytes, tightly packed); needs cfg.fast_blur_sigma != 0.
+int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out) {
+    if (!f || !out) return EKFVIO_EINVAL;
+    const KltFrame& fr = f->frames[f->cur];
+    if (!fr.valid || !f->blurred) return EKFVIO_ESTATE;
+    HIPF(f, hipSetDevice(f->device));
+    HIPF(f, hipMemcpyAsync(out, f->blurred, (size_t)fr.w[0] * fr.h[0], hipMemcpyDeviceToHost, f->stream));
+    HIPF(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
 // EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame
 int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy) {
     if (!f) return EKFVIO_EINVAL;
-    if (f->cfg.fast_blur_sigma != 0.f) {
-        f->last_error = "FAST_BLUR_SIGMA != 0 (cv::GaussianBlur before FAST) is not implemented";
+    if (f->cfg.fast_blur_sigma != 0.f && !(f->cfg.fast_blur_sigma > 0.f)) {
+        f->last_error = "fast_blur_sigma must be >= 0";  // cv::GaussianBlur would derive sigma from the kernel size
         return EKFVIO_EINVAL;
     }
     if (f->cfg.min_new_feature_dist < 0 || f->cfg.min_new_feature_dist > 64 * OCC_PASSES / 2 - 1) {
@@ -419,7 +486,7 @@ int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy) {
     HIPF(f, hipSetDevice(f->device));
     if (added) *added = 0;
     if (f->N >= f->cfg.max_features) return EKFVIO_OK;  // "if (tc_ekf.features.size() < NUM_FEATURES)" (:236)
-    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1);
+    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1, f->cfg.fast_blur_sigma != 0.f);
     if (rc != EKFVIO_OK) return rc;
     const KltFrame& fr = f->frames[f->cur];
     const int w = fr.w[0], h = fr.h[0];

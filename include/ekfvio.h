@@ -66,7 +66,7 @@ typedef struct ekfvio_config {
     int32_t inverse_image_scale;           /* INVERSE_IMAGE_SCALE: frames are resized to (w/s, h/s), K/s; reference default 4, here 1 */
     int32_t fast_threshold;                /* FAST_THRESHOLD 50 */
     int32_t min_new_feature_dist;          /* MIN_NEW_FEATURE_DIST 30 (radius of the occupancy circles) */
-    float fast_blur_sigma;                 /* FAST_BLUR_SIGMA 0 = off; non-zero is rejected (not implemented) */
+    float fast_blur_sigma;                 /* FAST_BLUR_SIGMA: 0 = off (reference default), > 0: cv::GaussianBlur(5x5, sigma) before FAST */
     int32_t replenish;                     /* 1: ekfvio_step_image also runs replenishFeatures */
     int32_t sample_based_uncertainty;      /* 0 (reference behaviour): R = 1e-5 I px^2 (estimateUncertainty, KLTTracker.cpp:100-106);
                                               1: R from estimateUncertaintySampleBased (:111-175, dead code there) */
@@ -159,9 +159,12 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
  * exist.  `added` (may be NULL) receives the number of new landmarks, new_px_xy (may be NULL, room for
  * 2*max_features ints) their pixels. */
 int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy);
-/* Test hook: cv::FAST(level 0 of the current frame, threshold, nonmax), TYPE_9_16, keypoints in raster order. */
+/* Test hook: cv::FAST(level 0 of the current frame, blurred first if cfg.fast_blur_sigma != 0, threshold, nonmax),
+ * TYPE_9_16, keypoints in raster order. */
 int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score,
                        int32_t* count);
+/* Test hook: the blurred level 0 (w*h bytes) the last FAST run saw; cfg.fast_blur_sigma must be non-zero. */
+int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out);
 /* EKFVIO::imu_callback (EKFVIO.cpp:113-115) is a logging stub in the reference; kept so the
  * node shim has somewhere to deliver IMU records.  No arithmetic. */
 int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float accel[3]);

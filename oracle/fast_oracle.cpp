@@ -188,6 +188,57 @@ int orc_frame_resize(const uint8_t* src, int w, int h, int stride, int inv_scale
 
 // cv::FAST(img, kp, threshold, nonmax): keypoints in raster order; returns the number found
 // (xy/score filled up to `cap` entries)
+// cv::GaussianBlur(img, out, Size(5,5), sigma) on an 8-bit image as replenishFeatures calls it when
+// FAST_BLUR_SIGMA != 0 (EKFVIO.cpp:228-232).  OpenCV 3.x (the reference's era: ROS Kinetic ships 3.3.1), 8-bit path of
+// createSeparableLinearFilter (modules/imgproc/src/filter.cpp) with getGaussianKernel (smooth.cpp):
+//   * float kernel: cf[i] = (float)exp(-0.5/sigma^2 * (i-2)^2), sum in double, cf[i] = (float)(cf[i] * (1/sum));
+//   * symmetric smoothing kernels on 8-bit data run in fixed point: k[i] = cvRound(cf[i] * 256) (float product, round
+//     half to even), row pass = exact int sums, column pass = exact int sums, result (v + 2^15) >> 16, saturated;
+//   * BORDER_DEFAULT = BORDER_REFLECT_101.
+// No intermediate rounding happens between the passes, so the result is the exact 2-D integer sum.
+// PARITY STATUS: unpinned (OpenCV absent, version unpinned; 3.4.2+ switched 8-bit Gaussians to a ufixedpoint16 kernel
+// whose taps are normalised to sum to 256 exactly).
+void orc_gauss5_kernel(float sigma, int k[5]) {
+    float cf[5];
+    const double scale2x = -0.5 / ((double)sigma * (double)sigma);
+    double sum = 0;
+    for (int i = 0; i < 5; i++) {
+        const double x = i - 2.0;
+        cf[i] = (float)std::exp(scale2x * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 5; i++) {
+        cf[i] = (float)(cf[i] * sum);
+        k[i] = cv_round(cf[i] * 256.f);
+    }
+}
+
+int orc_gaussian_blur5(const uint8_t* img, int w, int h, int stride, float sigma, uint8_t* out) {
+    if (!(sigma > 0.f) || w < 2 || h < 2) return -1;
+    int k[5];
+    orc_gauss5_kernel(sigma, k);
+    auto r101 = [](int p, int len) {
+        while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+        return p;
+    };
+    std::vector<int> row((size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int a = 0;
+            for (int j = 0; j < 5; j++) a += k[j] * (int)img[(size_t)y * stride + r101(x + j - 2, w)];
+            row[(size_t)y * w + x] = a;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int a = 0;
+            for (int i = 0; i < 5; i++) a += k[i] * row[(size_t)r101(y + i - 2, h) * w + x];
+            a = (a + (1 << 15)) >> 16;
+            out[(size_t)y * w + x] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+        }
+    return 0;
+}
+
 int orc_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax, int cap, int* xy, int* score_out) {
     std::vector<int> sc;
     fast_score_map(img, w, h, stride, threshold, sc);

@@ -72,6 +72,8 @@ def _declare(lib):
     lib.orc_set_threads.argtypes = [i32]
     lib.orc_max_threads.restype = i32
     lib.orc_frame_resize.argtypes = [u8p, i32, i32, i32, i32, u8p]
+    lib.orc_gaussian_blur5.argtypes = [u8p, i32, i32, i32, C.c_float, u8p]
+    lib.orc_gauss5_kernel.argtypes = [C.c_float, ip]
     lib.orc_fast_detect.argtypes = [u8p, i32, i32, i32, i32, i32, i32, ip, ip]
     lib.orc_circle_fill.argtypes = [u8p, i32, i32, i32, i32, i32]
     lib.orc_replenish.argtypes = [u8p, i32, i32, i32, fpp, i32, i32, i32, i32, i32, i32, ip]
@@ -269,6 +271,23 @@ def frame_resize(img, inv_scale):
     rc = oracle_lib().orc_frame_resize(_p(img, C.c_uint8), w, h, w, int(inv_scale), _p(out, C.c_uint8))
     assert rc == 0
     return out
+
+
+def gaussian_blur5(img, sigma):
+    """cv::GaussianBlur(img, Size(5,5), sigma) on an 8-bit image (OpenCV 3.x fixed-point path, reflect-101)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros_like(img)
+    rc = oracle_lib().orc_gaussian_blur5(_p(img, C.c_uint8), w, h, w, float(sigma), _p(out, C.c_uint8))
+    assert rc == 0
+    return out
+
+
+def gauss5_kernel(sigma):
+    """the five fixed-point taps (x256) of that blur"""
+    k = np.zeros(5, np.int32)
+    oracle_lib().orc_gauss5_kernel(float(sigma), k.ctypes.data_as(C.POINTER(C.c_int)))
+    return k
 
 
 def fast_detect(img, threshold=50, nonmax=True):

@@ -120,3 +120,27 @@ def test_replenish_first_fit_invariants():
     for x, y in again:
         assert all((x - ex_x) ** 2 + (y - ex_y) ** 2 > 29 ** 2 for ex_x, ex_y in np.rint(ex))
     assert len(replenish(img, np.zeros((100, 2), np.float32), 100)) == 0
+
+
+def test_gaussian_blur5_known_answers():
+    """cv::GaussianBlur(5x5, sigma) restated for 8-bit images (OpenCV 3.x fixed-point path).  Known answers from the
+    published definition: taps = round(256 * normalised Gaussian), symmetric; the blur equals the float correlation
+    with taps/256 under mirror (reflect-101) borders up to the final rounding; an impulse reproduces the outer product
+    of the taps."""
+    from oracle import gauss5_kernel, gaussian_blur5
+    from scipy.ndimage import correlate1d
+    k = gauss5_kernel(1.0)
+    assert list(k) == [14, 63, 103, 63, 14]  # exp(-x^2/2) / sum * 256, rounded
+    assert list(gauss5_kernel(0.5)) == [0, 27, 201, 27, 0]
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53)).astype(np.uint8)
+    for sigma in (0.7, 1.0, 2.5):
+        kk = gauss5_kernel(sigma).astype(np.float64) / 256.0
+        ref = correlate1d(correlate1d(img.astype(np.float64), kk, axis=0, mode="mirror"), kk, axis=1, mode="mirror")
+        got = gaussian_blur5(img, sigma).astype(np.float64)
+        assert np.abs(got - np.minimum(ref, 255.0)).max() <= 0.5 + 1e-9
+    imp = np.zeros((11, 11), np.uint8)
+    imp[5, 5] = 255
+    out = gaussian_blur5(imp, 1.0).astype(np.int64)
+    want = (255 * np.outer(k, k) + (1 << 15)) >> 16
+    assert np.array_equal(out[3:8, 3:8], want) and out.sum() == want.sum()

@@ -7,7 +7,7 @@ import pytest
 from PIL import Image
 
 from ekf_vio_amd import EKFVIO, KLTTracker, TightlyCoupledEKF, capi
-from oracle import fast_detect, frame_resize, replenish
+from oracle import fast_detect, frame_resize, gaussian_blur5, replenish
 
 pytestmark = pytest.mark.gpu
 IMG = os.path.join(os.path.dirname(__file__), "golden", "images")
@@ -124,4 +124,39 @@ def test_step_image_with_replenish_runs_the_whole_addframe_sequence():
     good = st["del_flag"][:n1] == 0
     d = moved[good] * np.array([K[0], K[4]], np.float32) - ref[good].astype(np.float32)
     assert good.sum() >= n1 // 2 and np.all(np.abs(np.median(d, axis=0) - np.array([-21.0, -7.0])) < 0.05)
+    v.tc_ekf.close()
+
+
+@pytest.mark.parametrize("sigma,scale,crop", [(1.0, 1, None), (0.7, 1, (251, 333)), (2.5, 2, None), (1.5, 1, (37, 53))])
+def test_gaussian_blur_before_fast_bit_exact(sigma, scale, crop):
+    """FAST_BLUR_SIGMA != 0 (EKFVIO.cpp:228-232): cv::GaussianBlur(5x5, sigma) in OpenCV 3.x's 8-bit fixed-point
+    arithmetic, reflect-101 border, then FAST and the replenishment on the blurred image — all integer, all
+    bit-exact against the oracle."""
+    import ctypes as C
+    img = grey("640_480_test")
+    if crop:
+        img = np.ascontiguousarray(img[:crop[0], :crop[1]])
+    v = EKFVIO(max_features=80, fast_blur_sigma=sigma, inverse_image_scale=scale, fast_threshold=20)
+    assert v.addFrame(1.0, img, K) == capi.OK
+    base = frame_resize(img, scale) if scale > 1 else img
+    want = gaussian_blur5(base, sigma)
+    xy, sc = v.fast(20, True)
+    got = np.zeros_like(want)
+    v.tc_ekf._chk(v.tc_ekf.lib.ekfvio_test_blurred_level0(v.tc_ekf.h, got.ctypes.data_as(C.POINTER(C.c_uint8))))
+    assert np.array_equal(got, want)
+    rxy, rsc = fast_detect(want, 20, True)
+    assert np.array_equal(xy, rxy) and np.array_equal(sc, rsc)
+    px = v.replenishFeatures()
+    ref = replenish(want, np.zeros((0, 2), np.float32), 80, threshold=20)
+    assert np.array_equal(px, ref)
+    if crop is None and scale == 1:
+        assert len(ref) > 5
+    v.tc_ekf.close()
+
+
+def test_negative_blur_sigma_is_rejected():
+    v = EKFVIO(max_features=8, fast_blur_sigma=-1.0)
+    v.addFrame(1.0, grey("640_480_test"), K)
+    with pytest.raises(capi.EkfvioError):
+        v.replenishFeatures()
     v.tc_ekf.close()
