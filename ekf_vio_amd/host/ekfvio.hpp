@@ -15,7 +15,11 @@
 // + step).  Errors the reference would ROS_ASSERT on surface as ekfvio::Error.
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -31,6 +35,103 @@ using Vector3f = std::array<float, 3>;
 struct Error : std::runtime_error {
     int code;
     Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// EKFVIO::EKFVIO's parameter block (EKFVIO.cpp:19-67, defaults Params.h:18-125) without ROS: the node's private
+// parameter names (without the "~") mapped onto ekfvio_config; node-level names (topics, frames, switches) are kept as
+// strings for the node shim; parameters of subsystems the reference no longer calls (moba / sba / depth updates /
+// variance boxes, all unused on the hot path) are accepted and ignored.  Unknown names are an error (a typo in a launch
+// file should not pass silently).  Values arrive as text, as in a launch file or a `rosparam dump`.
+struct Params {
+    ekfvio_config cfg;
+    std::map<std::string, std::string> node;  // odom_topic, camera_topic, base_frame, use_imu, publish_insight, ...
+
+    Params() {
+        ekfvio_default_config(&cfg);
+        cfg.inverse_image_scale = 4;  // D_INVERSE_IMAGE_SCALE (Params.h:28); the C-ABI's own default is 1
+        node = {{"publish_insight", "true"}, {"insight_topic", "invio/insight"}, {"insight_camera_info_topic", "invio/camera_info"},
+                {"analyze_runtime", "true"}, {"odom_topic", "invio/odom"}, {"odom_frame", "invio_odom"},
+                {"point_topic", "invio/points"}, {"camera_topic", "/camera/image_rect"}, {"base_frame", "base_link"},
+                {"world_frame", "world"}, {"camera_frame", "camera"}, {"imu_topic", "imu/measurement"},
+                {"imu_frame", "imu"}, {"use_imu", "true"}};
+    }
+
+    static double number(const std::string& key, const std::string& v) {
+        char* end = nullptr;
+        const double x = std::strtod(v.c_str(), &end);
+        if (end == v.c_str() || *end != '\0' || !std::isfinite(x)) throw Error(EKFVIO_EINVAL, "parameter " + key + ": not a number: " + v);
+        return x;
+    }
+    static int integer(const std::string& key, const std::string& v) {
+        const double x = number(key, v);
+        if (x != std::floor(x) || std::fabs(x) > 1e9) throw Error(EKFVIO_EINVAL, "parameter " + key + ": not an integer: " + v);
+        return (int)x;
+    }
+
+    void set(std::string key, const std::string& value) {
+        while (!key.empty() && (key[0] == '~' || key[0] == '/')) key.erase(0, 1);
+        const size_t slash = key.rfind('/');  // "/ekf_vio/num_features" from a rosparam dump
+        if (slash != std::string::npos) key = key.substr(slash + 1);
+        if (key == "num_features") cfg.max_features = integer(key, value);
+        else if (key == "fast_threshold") cfg.fast_threshold = integer(key, value);
+        else if (key == "fast_blur_sigma") cfg.fast_blur_sigma = (float)number(key, value);
+        else if (key == "inverse_image_scale") cfg.inverse_image_scale = integer(key, value);  // Frame.cpp:15-42; integral scales only
+        else if (key == "kill_pad") cfg.kill_pad = integer(key, value);
+        else if (key == "min_klt_eigen_val") cfg.klt_min_eigen = (float)number(key, value);
+        else if (key == "min_new_feature_dist") cfg.min_new_feature_dist = (int)number(key, value);  // a double there, used as a radius
+        else if (key == "max_pyramids") cfg.klt_max_pyramid_level = integer(key, value);
+        else if (key == "klt_window_size") cfg.klt_window_size = integer(key, value);
+        else if (key == "default_point_depth") cfg.default_point_depth = (float)number(key, value);
+        else if (key == "default_point_depth_variance") cfg.default_point_depth_variance = (float)number(key, value);
+        else if (key == "default_point_homogenous_variance") cfg.default_point_homogenous_variance = (float)number(key, value);
+        else if (key == "frame_buffer_size") {
+            if (integer(key, value) != 2) throw Error(EKFVIO_EINVAL, "frame_buffer_size: the device keeps exactly two frames (Params.h:58)");
+        } else if (node.count(key)) node[key] = value;
+        else if (ignored().count(key)) (void)number(key, value);
+        else throw Error(EKFVIO_EINVAL, "unknown parameter: " + key);
+    }
+
+    static Params fromMap(const std::map<std::string, std::string>& kv) {
+        Params p;
+        for (const auto& e : kv) p.set(e.first, e.second);
+        return p;
+    }
+    // "key: value" lines (the flat YAML a launch file's <rosparam> block or `rosparam dump` of the node produces);
+    // '#' starts a comment, quotes around values are dropped.
+    static Params fromFile(const std::string& path) {
+        std::ifstream in(path);
+        if (!in) throw Error(EKFVIO_EINVAL, "cannot open " + path);
+        Params p;
+        std::string line;
+        while (std::getline(in, line)) {
+            const size_t hash = line.find('#');
+            if (hash != std::string::npos) line.erase(hash);
+            const size_t colon = line.find(':');
+            if (colon == std::string::npos) {
+                if (line.find_first_not_of(" \t\r") != std::string::npos) throw Error(EKFVIO_EINVAL, "not a 'key: value' line: " + line);
+                continue;
+            }
+            auto trim = [](std::string t) {
+                const size_t a = t.find_first_not_of(" \t\r\"'"), b = t.find_last_not_of(" \t\r\"'");
+                return a == std::string::npos ? std::string() : t.substr(a, b - a + 1);
+            };
+            p.set(trim(line.substr(0, colon)), trim(line.substr(colon + 1)));
+        }
+        return p;
+    }
+
+   private:
+    static const std::map<std::string, int>& ignored() {
+        static const std::map<std::string, int> names = {
+            {"border_weight_exponent", 0}, {"start_feature_count", 0}, {"dangerous_mature_feature_count", 0},
+            {"minimum_trackable_features", 0}, {"minimum_keyframe_count_for_optimization", 0},
+            {"maximum_keyframe_count_for_optimization", 0}, {"depth_translation_ratio", 0}, {"max_depth_updates_per_frame", 0},
+            {"maximum_reprojection_error", 0}, {"moba_candidate_variance", 0}, {"maximum_candidate_reprojection_error", 0},
+            {"eps_moba", 0}, {"eps_sba", 0}, {"huber_width", 0}, {"minumum_depth_determinant", 0}, {"moba_max_iterations", 0},
+            {"sba_max_iterations", 0}, {"max_point_z", 0}, {"min_point_z", 0}, {"min_variance_box_size", 0},
+            {"max_variance_box_size", 0}};
+        return names;
+    }
 };
 
 // Frame.h:25-41 without OpenCV: 8-bit single-channel image + intrinsics + stamp.
@@ -171,6 +272,9 @@ class EKFVIO {
    public:
     explicit EKFVIO(int max_features = 100, int device = 0, const ekfvio_config* cfg = nullptr)
         : tc_ekf(max_features, device, cfg), tracker(tc_ekf) {}
+    // the node's constructor (EKFVIO.cpp:19-67): parameters by the reference's names (see Params)
+    explicit EKFVIO(const Params& p, int device = 0) : tc_ekf(p.cfg.max_features, device, &p.cfg), tracker(tc_ekf), params(p.node) {}
+    std::map<std::string, std::string> params;  // node-level parameters (topics, frames, switches) for the ROS side
     TightlyCoupledEKF tc_ekf;
     KLTTracker tracker;
 

@@ -5,10 +5,12 @@
 // R = 1e-5 I, every landmark measured) through ekfvio::TightlyCoupledEKF and prints the
 // final odometry next to the ground truth, the checkSigma numbers and the step rate.
 // Usage: ekfvio_replay [landmarks=256] [frames=300] [seed=0] [dt=0.0333333]
+//        ekfvio_replay --print-config [params.yaml]   (no GPU work: the node's parameter file -> ekfvio_config as JSON)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "ekfvio.hpp"
 
@@ -47,7 +49,33 @@ Q mul(Q a, Q b) {
 }
 }  // namespace
 
+static int print_config(const char* path) {
+    try {
+        const ekfvio::Params p = path ? ekfvio::Params::fromFile(path) : ekfvio::Params();
+        const ekfvio_config& c = p.cfg;
+        std::printf("{\"max_features\": %d, \"fast_threshold\": %d, \"fast_blur_sigma\": %.9g, \"inverse_image_scale\": %d, "
+                    "\"kill_pad\": %d, \"klt_min_eigen\": %.9g, \"min_new_feature_dist\": %d, \"klt_max_pyramid_level\": %d, "
+                    "\"klt_window_size\": %d, \"default_point_depth\": %.9g, \"default_point_depth_variance\": %.9g, "
+                    "\"default_point_homogenous_variance\": %.9g, \"sample_based_uncertainty\": %d, \"node\": {",
+                    c.max_features, c.fast_threshold, (double)c.fast_blur_sigma, c.inverse_image_scale, c.kill_pad,
+                    (double)c.klt_min_eigen, c.min_new_feature_dist, c.klt_max_pyramid_level, c.klt_window_size,
+                    (double)c.default_point_depth, (double)c.default_point_depth_variance,
+                    (double)c.default_point_homogenous_variance, c.sample_based_uncertainty);
+        bool first = true;
+        for (const auto& e : p.node) {
+            std::printf("%s\"%s\": \"%s\"", first ? "" : ", ", e.first.c_str(), e.second.c_str());
+            first = false;
+        }
+        std::printf("}}\n");
+        return 0;
+    } catch (const ekfvio::Error& e) {
+        std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
+        return 2;
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::strcmp(argv[1], "--print-config") == 0) return print_config(argc > 2 ? argv[2] : nullptr);
     const int N = argc > 1 ? std::atoi(argv[1]) : 256;
     const int frames = argc > 2 ? std::atoi(argv[2]) : 300;
     const uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 0;

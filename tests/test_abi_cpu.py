@@ -68,3 +68,65 @@ def test_create_fails_loudly_without_gpu(gpu_available):
     from ekf_vio_amd import EkfvioError, TightlyCoupledEKF
     with pytest.raises(EkfvioError):
         TightlyCoupledEKF(max_features=4)
+
+
+def _print_config(tmp_path, text):
+    import json
+    from ekf_vio_amd import _build
+    _build.build()
+    exe = _build.build_host()
+    args = [exe, "--print-config"]
+    if text is not None:
+        f = tmp_path / "params.yaml"
+        f.write_text(text)
+        args.append(str(f))
+    out = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    return out.returncode, (json.loads(out.stdout) if out.returncode == 0 else out.stderr)
+
+
+def test_node_parameter_names_map_onto_the_config(tmp_path):
+    """the node's private ROS parameters (EKFVIO.cpp:19-67, defaults Params.h) reach ekfvio_config
+    through the C++ shim's ekfvio::Params, by the reference's own names; no GPU involved."""
+    rc, d = _print_config(tmp_path, None)
+    assert rc == 0
+    # Params.h defaults, incl. D_INVERSE_IMAGE_SCALE 4 (the C-ABI's own default is 1) and the node-level strings
+    assert (d["max_features"], d["fast_threshold"], d["inverse_image_scale"], d["kill_pad"]) == (100, 50, 4, 11)
+    assert d["min_new_feature_dist"] == 30 and d["klt_window_size"] == 21 and d["klt_max_pyramid_level"] == 3
+    assert d["fast_blur_sigma"] == 0 and d["sample_based_uncertainty"] == 0
+    assert d["node"]["odom_topic"] == "invio/odom" and d["node"]["camera_topic"] == "/camera/image_rect"
+    assert d["node"]["imu_topic"] == "imu/measurement" and d["node"]["base_frame"] == "base_link"
+    # a parameter file in the layout of the reference's params/*.yaml: hot-path names, names of subsystems the
+    # reference no longer calls (accepted, ignored), comments, a namespaced key, a quoted string
+    text = """
+min_new_feature_dist: 25.0
+num_features: 400
+fast_threshold: 45   # corner threshold
+fast_blur_sigma: 1.5
+depth_translation_ratio: 0.01
+default_point_depth: 0.75
+default_point_depth_variance: 1000
+minumum_depth_determinant: 0.00001
+# how many points to update per frame
+max_depth_updates_per_frame: 400
+huber_width: 1e-6
+moba_max_iterations: 10
+inverse_image_scale: 2
+publish_insight: false
+/ekf_vio/kill_pad: 13
+~min_klt_eigen_val: 0.001
+max_pyramids: 2
+klt_window_size: 15
+odom_topic: "vio/odom"
+frame_buffer_size: 2
+"""
+    rc, d = _print_config(tmp_path, text)
+    assert rc == 0, d
+    assert (d["max_features"], d["fast_threshold"], d["inverse_image_scale"], d["kill_pad"]) == (400, 45, 2, 13)
+    assert d["min_new_feature_dist"] == 25 and d["fast_blur_sigma"] == 1.5
+    assert d["default_point_depth"] == 0.75 and d["default_point_depth_variance"] == 1000
+    assert abs(d["klt_min_eigen"] - 1e-3) < 1e-9 and d["klt_max_pyramid_level"] == 2 and d["klt_window_size"] == 15
+    assert d["node"]["publish_insight"] == "false" and d["node"]["odom_topic"] == "vio/odom"
+    # what the reference would silently accept but cannot mean anything here is an error, not a surprise
+    for bad in ("num_feature: 10\n", "fast_threshold: many\n", "frame_buffer_size: 3\n", "inverse_image_scale: 2.5\n", "just words\n"):
+        rc, err = _print_config(tmp_path, bad)
+        assert rc == 2 and "error" in err, (bad, err)
