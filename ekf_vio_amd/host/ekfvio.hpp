@@ -274,9 +274,9 @@ class EKFVIO {
         : tc_ekf(max_features, device, cfg), tracker(tc_ekf) {}
     // the node's constructor (EKFVIO.cpp:19-67): parameters by the reference's names (see Params)
     explicit EKFVIO(const Params& p, int device = 0) : tc_ekf(p.cfg.max_features, device, &p.cfg), tracker(tc_ekf), params(p.node) {}
-    std::map<std::string, std::string> params;  // node-level parameters (topics, frames, switches) for the ROS side
     TightlyCoupledEKF tc_ekf;
     KLTTracker tracker;
+    std::map<std::string, std::string> params;  // node-level parameters (topics, frames, switches) for the ROS side
 
     // EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the frame pushed last: FAST-9/16 + occupancy first fit +
     // addNewFeatures, all on the device.  Returns the number of landmarks added.  With cfg.replenish = 1
