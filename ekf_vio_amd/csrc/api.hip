@@ -158,6 +158,8 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
         f->num_cus = prop.multiProcessorCount;
         const char* e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
         if (e) f->sweep_mode = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
+        if (e) f->fuse_gather = atoi(e) ? 1 : 0;
     }
     HIPC(f, dev_alloc(f->stream, &f->Km, pm));
     HIPC(f, dev_alloc(f->stream, &f->Wt, pm));

@@ -422,6 +422,67 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
     if (bad && tid == 0) atomicOr(info, 1);
 }
 
+#include "gather_body.inc"
+
+// The measurement gather and the factorisation of the first diagonal tile in ONE launch.  Workgroup 0 forms the first
+// 64x64 tile of A = (H Sigma H^T + R)^T straight from Sigma (the same elements, through the same gather_a_elem, as the
+// gather writes to Saug) and factors it; every other workgroup is a gather workgroup.  The pivot chain is
+// latency-bound and runs 2x longer when its compute unit is shared, so the launch asks for more than half a compute
+// unit's LDS per workgroup (EKF_GATHER_POTRF_LDS): one workgroup per compute unit, the chain has its own.
+__global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float* __restrict__ L, int ldl, float* __restrict__ Linv,
+                                                           int* info, long long* dbg) {
+    extern __shared__ float dyn_lds[];
+    const int tid = threadIdx.x;
+#define GSTAMP_(slot)                                                                               \
+    do {                                                                                            \
+        if (dbg && tid == 0) dbg[1000 + (slot)] = (long long)__builtin_amdgcn_s_memtime();          \
+    } while (0)
+    if (blockIdx.x != 0) {
+        gather_body(ga, (int)blockIdx.x - 1, dyn_lds);
+        if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) dbg[1004] = (long long)__builtin_amdgcn_s_memtime();
+        if (dbg && tid == 0 && blockIdx.x == 1) dbg[1005] = (long long)__builtin_amdgcn_s_memtime();
+        return;
+    }
+    GSTAMP_(0);
+    float* A = dyn_lds;
+    float* Tinv = dyn_lds + PB * PLD;
+    const int m = ga.m;
+    // lanes along c: Sigma(idx[c], idx[r]) = P[idx[r]*ld + idx[c]] is (nearly) contiguous in c
+    const int c = tid & 63;
+    const int sc = (c < m) ? ga.idx[c] : 0;
+    // two batches of loads (row indices and R entries, then the Sigma elements), each fully in flight before its first use:
+    // clamped, unconditional addresses, the masks are applied to the values
+    int ir[16];
+    float v[16], rd[16], ro[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ps++) {
+        const int rc = min((tid >> 6) + 4 * ps, m - 1);
+        ir[ps] = ga.idx[rc];
+        rd[ps] = ga.Rm[2 * rc];
+        ro[ps] = ga.Rm[2 * rc + 1];
+    }
+#pragma unroll
+    for (int ps = 0; ps < 16; ps++) asm volatile("" : "+v"(ir[ps]));
+#pragma unroll
+    for (int ps = 0; ps < 16; ps++) v[ps] = ga.P[(size_t)ir[ps] * ga.ld + sc];
+#pragma unroll
+    for (int ps = 0; ps < 16; ps++) asm volatile("" : "+v"(v[ps]));
+#pragma unroll
+    for (int ps = 0; ps < 16; ps++) {
+        const int r = (tid >> 6) + 4 * ps;
+        A[c * PLD + r] = gather_a_elem(v[ps], r, c, m, rd[ps], ro[ps]);
+    }
+    __syncthreads();
+    GSTAMP_(1);
+    const bool bad = potrf64_lds(A, Tinv, tid);
+    GSTAMP_(2);
+    store_tile_lower(A, L, ldl, tid);
+    store_inv(Tinv, Linv, tid);
+    if (bad && tid == 0) atomicOr(info, 1);
+    GSTAMP_(3);
+#undef GSTAMP_
+}
+
 // Block step k of the right-looking sweep over the augmented matrix [A; X; I].
 // grid.x = r(r+1)/2 triangular tiles of A (r = mb-1-k) + rb*r rectangular tiles of the extra
 // row blocks (X: the forward substitution Y L^T = X rides along; I: yields L^-T).
@@ -797,7 +858,20 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps);
 }
 
-void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld) {
+#define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
+void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad) {
+    if (!f->gather_attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  EKF_GATHER_POTRF_LDS);
+        f->gather_attr_set = true;
+    }
+    const GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+    const int nb2 = (m_pad / 64) * (f->ldp / 64);  // 64x64 transposing tiles of Wt
+    hipLaunchKernelGGL(gather_potrf_kernel, dim3(1 + ga.nb1 + nb2), dim3(256), EKF_GATHER_POTRF_LDS, f->stream, ga, f->Laug, f->ld_aug,
+                       f->Linv, f->info, f->sweep_dbg);
+}
+
+void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done) {
     ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad);
     const int mb = m_pad / PB;
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
@@ -813,7 +887,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
                            idb0, f->info, f->sweep_sync, f->sweep_dbg);
         return;
     }
-    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info);
+    if (!first_tile_done) hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info);
     // many tiles per step: panel blocks once per step in a launch of their own instead of twice per tile
     const bool split = mb >= EKF_SWEEP_SPLIT_MB;
     for (int k = 0; k + 1 < mb; k++) {

@@ -95,6 +95,8 @@ struct ekfvio_filter {
     float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
     int* sweep_sync = nullptr; // [2*m_cap/64 + 4] ready/done counters + abort flag of the persistent sweep
     int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
+    int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
+    bool gather_attr_set = false;
     int num_cus = 0;
     int last_m = 0;            // measurement rows of the most recent update (shape of its GEMMs)
     long long* sweep_dbg = nullptr;  // [512] s_memtime stamps of the persistent sweep (diagnostic; null = off)
@@ -224,7 +226,9 @@ int add_features_device(ekfvio_filter* f, int k);
 void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);
 // Augmented blocked Cholesky sweep (chol.hip): Saug = [A; X; I] (row blocks of 64; A is
 // m_pad x m_pad, X has n_pad rows) -> Laug = [L; X L^-T; L^-T], both ld x m_pad column-major.
-void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld);
+void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld,
+                       bool first_tile_done = false);
+void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad);
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);
 // K = X A^-1 (n rows, ldk) from the sweep output: K = Y L^-1 (+ optional residual refinement).
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,

@@ -558,101 +558,11 @@ __global__ void add_noise_flush_kernel(float* P, int ld, int n, float dt) {
 // of frame *frame_counter is used and the counter advances modulo `frames`.
 __global__ __launch_bounds__(1024) void update_bookkeeping_kernel(BookArgs a) { bookkeeping_body<1024>(a); }
 
-// A = (H Sigma H^T + R)^T (:559-561, :578), padded with the identity.  The reference hands
-// S.transpose() to SimplicialLDLT, which reads the LOWER triangle of what it is given, i.e.
-// the UPPER triangle of S.  Sigma is only symmetric to rounding (~1e-6) and S^-1 amplifies
-// by 1/lambda_min ~ 5e4, so the choice of triangle is visible at the 1e-4 level: store
-// A(r,c) = S(c,r) so that the Cholesky kernels (which read the lower triangle) factor the
-// same numbers as the reference.  C = Sigma H^T (columns of Sigma); Wt = (H Sigma)^T (rows
-// of Sigma, transposed so that it is state-major).
-// A, the identity and C are one thread per element (coalesced along the state index); Wt goes through 64x64
-// LDS tiles in extra workgroups of the same launch.
-#define GC 4  // measurement columns per element workgroup of gather_kernel
-__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ P, int ld, int n,
-                                                     const int* __restrict__ idx, const float* __restrict__ Rm, int m,
-                                                     int m_pad, int n_pad, float* Saug, int lda, float* Wt,
-                                                     const float* __restrict__ zrow, const float* __restrict__ mu, float* G,
-                                                     int gx, int nb1) {
+#include "gather_body.inc"
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     __shared__ float tile[64 * 65];
-    if ((int)blockIdx.x >= nb1) {
-        // ---- Wt = (H Sigma)^T: Wt(i, c) = Sigma(idx[c], i) = P[i*ld + idx[c]] ----
-        // For a fixed i the wanted elements are (nearly) contiguous in c, but Wt is contiguous in i: a 64x64 tile
-        // goes through LDS so that both the reads (lanes along c) and the writes (lanes along i) are coalesced.
-        // (Read straight, with lanes along i, every lane touches its own 64-B sector: 26 MB of sector traffic
-        // for 1.6 MB of data, the bulk of this kernel's time.)
-        const int tb = blockIdx.x - nb1, tiles_c = m_pad / 64;
-        const int c0 = (tb % tiles_c) * 64, i0 = (tb / tiles_c) * 64;
-        const int l64 = threadIdx.x & 63, q4 = threadIdx.x >> 6;
-        const int c = c0 + l64;
-        const int sc = (c < m) ? idx[c] : -1;
-        float wv[16];  // all 16 loads in flight before the first LDS write
-        const int scl = max(sc, 0);
-#pragma unroll
-        for (int ps = 0; ps < 16; ps++) {
-            const int i = min(i0 + q4 + 4 * ps, n - 1);  // clamped: unconditional loads issue as one batch
-            wv[ps] = P[(size_t)i * ld + scl];
-        }
-#pragma unroll
-        for (int ps = 0; ps < 16; ps++) asm volatile("" : "+v"(wv[ps]));
-        // extra row n: -(z - H mu) (:554-555), so that the Joseph-1 GEMM yields K*y in column n
-        const bool has_n = (n >= i0 && n < i0 + 64);
-        const float ny = (has_n && sc >= 0) ? -(zrow[c] - mu[sc]) : 0.f;
-#pragma unroll
-        for (int ps = 0; ps < 16; ps++) {
-            const int ii = q4 + 4 * ps;
-            float w = (sc >= 0 && i0 + ii < n) ? wv[ps] : 0.f;
-            if (i0 + ii == n) w = ny;
-            tile[ii * 65 + l64] = w;
-        }
-        __syncthreads();
-        const int i = i0 + l64;
-#pragma unroll
-        for (int ps = 0; ps < 16; ps++) {
-            const int cc = q4 + 4 * ps, cw = c0 + cc;
-            if (i < ld) Wt[(size_t)cw * ld + i] = tile[l64 * 65 + cc];
-        }
-        return;
-    }
-    // ---- A = (H Sigma H^T + R)^T, the identity block and C = Sigma H^T: one thread per row, GC columns per workgroup
-    // (the row's own index lookups are shared by the GC columns and all their loads are in flight together) ----
-    const int x = (blockIdx.x % gx) * blockDim.x + threadIdx.x;
-    const int cbase = (blockIdx.x / gx) * GC;
-    const int r = x;
-    const int ir = (r < m) ? idx[r] : 0;
-    const float rd = (r < m) ? Rm[2 * r] : 0.f, ro = (r < m) ? Rm[2 * r + 1] : 0.f;
-    int scv[GC];
-    float sv[GC], cv[GC];
-#pragma unroll
-    for (int q = 0; q < GC; q++) scv[q] = (cbase + q < m) ? idx[cbase + q] : 0;
-#pragma unroll
-    for (int q = 0; q < GC; q++) {
-        const int c = cbase + q;
-        sv[q] = (x < m_pad && r < m && c < m) ? P[(size_t)ir * ld + scv[q]] : 0.f;  // Sigma(idx[c], idx[r]) = S(c,r)
-        cv[q] = (x < ld && c < m && x < n) ? P[(size_t)scv[q] * ld + x] : 0.f;    // Sigma(i, idx[c])
-    }
-#pragma unroll
-    for (int q = 0; q < GC; q++) {
-        const int c = cbase + q;
-        if (c >= m_pad) break;
-        if (x < m_pad) {
-            float v;
-            if (r < m && c < m) {
-                v = sv[q];
-                if (r == c)
-                    v = v + rd;
-                else if ((r ^ 1) == c)
-                    v = v + ro;  // R(c,r): the off-diagonal element of column r
-            } else {
-                v = (r == c) ? 1.f : 0.f;
-            }
-            Saug[(size_t)c * lda + r] = v;
-            Saug[(size_t)c * lda + m_pad + n_pad + r] = (r == c) ? 1.f : 0.f;  // identity block
-        }
-        if (x < ld) {
-            if (x < n_pad) Saug[(size_t)c * lda + m_pad + x] = cv[q];
-            if (c >= m) G[(size_t)c * ld + x] = 0.f;   // padding columns of G stay zero
-        }
-    }
+    gather_body(a, blockIdx.x, tile);
 }
 
 // (G = K*R - T[:, idx] and mu += K*y are epilogues of the two Joseph GEMMs: see GemmEpi.)
@@ -797,10 +707,14 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream,
                                make_book_args(f, m, d_z, d_R, d_pass, d_frame_counter));
         if (m > 0) {
-            const int gx = (std::max(ld, m_pad) + 255) / 256;
-            const int nb1 = gx * ((m_pad + GC - 1) / GC), nb2 = (m_pad / 64) * (ld / 64);  // element workgroups + 64x64 transposing tiles of Wt
-            hipLaunchKernelGGL(gather_kernel, dim3(nb1 + nb2), dim3(256), 0, f->stream, f->P, ld, n, f->idx, f->Rm, m,
-                               m_pad, n_pad, f->Saug, lda, f->Wt, f->yres, f->mu, f->Gm, gx, nb1);
+            if (f->sweep_mode == 0 && f->fuse_gather) {
+                // the gather and the factorisation of the first diagonal tile share one launch (chol.hip)
+                launch_gather_potrf(f, m, m_pad, n_pad);
+            } else {
+                const GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+                const int nb2 = (m_pad / 64) * (ld / 64);  // 64x64 transposing tiles of Wt
+                hipLaunchKernelGGL(gather_kernel, dim3(ga.nb1 + nb2), dim3(256), 0, f->stream, ga);
+            }
         }
     }
     GemmEpi e2;
@@ -812,7 +726,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     e2.frames = frames;
     if (m > 0) {
         // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
-        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda);
+        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, f->sweep_mode == 0 && f->fuse_gather);
         launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
         {
             // The two P-update GEMMs, back to back (one profiler scope, two launches):

@@ -22,3 +22,7 @@ for k in range((2 * N + 63) // 64 - 1):
 for k in range((2 * N + 63) // 64 - 1):
     b = 960 + 4 * k
     print("step %2d panel solve (wave 0): operand preload %5d  MFMA chain %5d  write-back %5d" % (k, v[b + 1] - v[b], v[b + 2] - v[b + 1], v[b + 3] - v[b + 2]))
+
+if v[1000]:
+    print("gather+potrf launch, chain workgroup: tile gather %d  factorisation %d  stores %d cycles; last gather workgroup ended %+d, first %+d cycles after the chain workgroup started"
+          % (v[1001] - v[1000], v[1002] - v[1001], v[1003] - v[1002], v[1004] - v[1000], v[1005] - v[1000]))
