@@ -701,13 +701,21 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     const int n_pad = round_up(n, EKF_TILE);
     const int lda = f->ld_aug;
     f->last_m = m;
+    // The gather and the first diagonal tile's factorisation share a launch while that launch is a single round of
+    // workgroups at one per compute unit (chol.hip: gather_potrf_kernel); beyond that (N = 1024: thousands of gather
+    // workgroups) the gather wants several workgroups per compute unit and the two stay separate.
+    bool fused_gather = false;
+    if (m > 0 && f->sweep_mode == 0 && f->fuse_gather) {
+        const int gx = (std::max(ld, m_pad) + 255) / 256;
+        fused_gather = 1 + gx * ((m_pad + GC * GCI - 1) / (GC * GCI)) + (m_pad / 64) * (ld / 64) <= f->num_cus;
+    }
     {
         ProfScope ps(f, PC_GATHER);
         if (!bookkeeping_done)
             hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream,
                                make_book_args(f, m, d_z, d_R, d_pass, d_frame_counter));
         if (m > 0) {
-            if (f->sweep_mode == 0 && f->fuse_gather) {
+            if (fused_gather) {
                 // the gather and the factorisation of the first diagonal tile share one launch (chol.hip)
                 launch_gather_potrf(f, m, m_pad, n_pad);
             } else {
@@ -726,7 +734,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     e2.frames = frames;
     if (m > 0) {
         // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
-        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, f->sweep_mode == 0 && f->fuse_gather);
+        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather);
         launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
         {
             // The two P-update GEMMs, back to back (one profiler scope, two launches):
