@@ -160,6 +160,8 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
         if (e) f->sweep_mode = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches
+        if (e) f->fuse_linearize = atoi(e) ? 1 : 0;
     }
     HIPC(f, dev_alloc(f->stream, &f->Km, pm));
     HIPC(f, dev_alloc(f->stream, &f->Wt, pm));

@@ -97,6 +97,7 @@ struct ekfvio_filter {
     int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
+    int fuse_linearize = 1;    // 1: structured process(dt) is one launch, the Jacobian blocks are formed inside it (EKFVIO_FUSE_LINEARIZE)
     int num_cus = 0;
     int last_m = 0;            // measurement rows of the most recent update (shape of its GEMMs)
     long long* sweep_dbg = nullptr;  // [512] s_memtime stamps of the persistent sweep (diagnostic; null = off)

@@ -377,6 +377,64 @@ __device__ inline float process_noise(int i, float dt) {
 // thread per element.  Every sum runs in ascending state index with separate multiply and
 // add (X = F*P first, then X*F^T), i.e. the order of the reference's sparse products.
 // ---------------------------------------------------------------------------------------
+// ---- the pieces of numericallyLinearizeProcess (:176-325) as device functions, shared by linearize_kernel's
+// formulation (one motion per lane) and by the propagation kernel when it linearises in place (LIN = true) ----
+// Derivative column e of landmark (u, v, rho): e = 0..8 -> d/d(base state 7+e) (a column of B, :223-253),
+// e = 9..11 -> d/d(own component e-9) (a column of D, :262-321).  bm[0] is the unperturbed base motion,
+// bm[1+2c] / bm[2+2c] the ones with base state 7+c at +delta / -delta.
+__device__ __forceinline__ void lin_column(const BaseMotion* bm, float u, float v, float rho, int e, float td, float out[3]) {
+    V3 hi, lo;
+    if (e < 9) {
+        hi = convolve_feature(bm[1 + 2 * e], u, v, rho);
+        lo = convolve_feature(bm[2 + 2 * e], u, v, rho);
+    } else {
+        const int c = e - 9;
+        float t0 = u, t1 = v, t2 = rho;
+        if (c == 0) t0 = plus_delta(t0);
+        if (c == 1) t1 = plus_delta(t1);
+        if (c == 2) t2 = plus_delta(t2);
+        hi = convolve_feature(bm[0], t0, t1, t2);
+        if (c == 0) t0 = minus_2delta(t0);
+        if (c == 1) t1 = minus_2delta(t1);
+        if (c == 2) t2 = minus_2delta(t2);
+        lo = convolve_feature(bm[0], t0, t1, t2);
+    }
+    out[0] = (hi.x - lo.x) / td;
+    out[1] = (hi.y - lo.y) / td;
+    out[2] = (hi.z - lo.z) / td;
+}
+// base motion variant v of the 19 the landmark rows need (0: unperturbed, 1+2c: column 7+c plus, 2+2c: minus)
+__device__ __forceinline__ BaseMotion lin_base_motion(const float* s_base, int v, float dt) {
+    float t[EKF_BASE];
+#pragma unroll
+    for (int i = 0; i < EKF_BASE; i++) t[i] = s_base[i];
+    if (v > 0) {
+        const int c = 7 + (v - 1) / 2;
+#pragma unroll
+        for (int i = 7; i < 16; i++) {
+            if (i == c) {
+                t[i] = plus_delta(t[i]);
+                if (((v - 1) & 1) == 1) t[i] = minus_2delta(t[i]);
+            }
+        }
+    }
+    return base_motion(t, dt);
+}
+// convolveBaseState at test point q (column q>>1 at +delta for even q, -delta for odd q) -> out[22]
+__device__ __forceinline__ void lin_base_test_point(const float* s_base, int q, float dt, float* out) {
+    const int j = q >> 1;
+    float t[EKF_BASE], o[EKF_BASE];
+#pragma unroll
+    for (int i = 0; i < EKF_BASE; i++) t[i] = (i == j) ? plus_delta(s_base[i]) : s_base[i];
+    if (q & 1) {
+#pragma unroll
+        for (int i = 0; i < EKF_BASE; i++) t[i] = (i == j) ? minus_2delta(t[i]) : t[i];
+    }
+    convolve_base(t, dt, o);
+#pragma unroll
+    for (int i = 0; i < EKF_BASE; i++) out[i] = o[i];
+}
+
 #define PT 16  // landmarks per tile side (landmark x landmark tiles)
 #define PC 3   // landmarks per base-row / base-column workgroup (3*PC <= 64)
 
@@ -386,13 +444,32 @@ __device__ __forceinline__ float predict_finish(float acc, int i, int j, float d
 }
 
 // grid.x = tiles_side^2 landmark tiles + (1 + chunks) base-row workgroups + chunks base-column workgroups
+//          (+ 1 bookkeeping workgroup with LIN and book.enabled)
+// LIN = true: process(dt) in ONE launch.  Every workgroup forms the Jacobian blocks it needs itself, with the device
+// functions linearize_kernel uses (same values, same bits) and straight into LDS: a landmark tile its 2 x 16 B and D
+// blocks (384 derivative columns over 256 threads), a base workgroup A (and the B, D of its three landmarks).  The
+// propagated mean is written by the diagonal tiles (landmarks) and base workgroup 0; the coming update's measurement
+// bookkeeping rides along as one more workgroup.  The redundant arithmetic (each landmark's columns are formed by
+// 2 * tiles_side workgroups) is ~1 % of an MI355X-microsecond; what it buys is a kernel boundary and a trip through HBM.
+template <bool LIN>
 __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restrict__ P, int ld, int N, int n,
                                                             const float* __restrict__ FA, const float* __restrict__ FB,
                                                             const float* __restrict__ FD, float dt,
-                                                            float* __restrict__ Pout, int tiles_side, int chunks) {
+                                                            float* __restrict__ Pout, int tiles_side, int chunks,
+                                                            const float* __restrict__ mu, float* __restrict__ mu_next, BookArgs book) {
     const int tid = threadIdx.x;
     const int ntile = tiles_side * tiles_side;
     __shared__ float sm[4096];
+    __shared__ float s_base[EKF_BASE];
+    __shared__ BaseMotion s_bm[19];
+    const float td = two_delta();
+    if (LIN) {
+        if (book.enabled && blockIdx.x == gridDim.x - 1) {
+            bookkeeping_body<256>(book);
+            return;
+        }
+        if (tid < EKF_BASE) s_base[tid] = mu[tid];
+    }
     if ((int)blockIdx.x < ntile) {
         float* sPbb = sm;                 // [81]      P(7+a, 7+b) at a*9+b
         float* sPbg = sm + 96;            // [PT][27]  P(7+a, 22+3g+s) at a*3+s
@@ -405,20 +482,67 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         const int tI = blockIdx.x / tiles_side, tJ = blockIdx.x % tiles_side;
         const int f0 = tI * PT, g0 = tJ * PT;
         if (tid < 81) sPbb[tid] = P[(size_t)(7 + tid % 9) * ld + 7 + tid / 9];
+        // LIN: the two derivative columns this thread forms: task = side*192 + landmark*12 + column, tasks tid and
+        // tid + 256 (< 384); on the diagonal tiles threads 128..143 propagate the landmarks' means in their second slot
+        float lu[2] = {0.f, 0.f}, lv[2] = {0.f, 0.f}, lrho[2] = {1.f, 1.f};
+        if (LIN) {
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                const int task = tid + 256 * sl;
+                int lmk = -1;
+                if (task < 384) lmk = ((task >= 192) ? g0 : f0) + (task % 192) / 12;
+                else if (tI == tJ && tid >= 128 && tid < 128 + PT) lmk = f0 + tid - 128;
+                if (lmk >= 0 && lmk < N) {
+                    lu[sl] = mu[EKF_BASE + 3 * lmk];
+                    lv[sl] = mu[EKF_BASE + 3 * lmk + 1];
+                    lrho[sl] = mu[EKF_BASE + 3 * lmk + 2];
+                }
+            }
+        }
         for (int e = tid; e < PT * 27; e += 256) {
             const int l = e / 27, w = e % 27;
             const int f = f0 + l, g = g0 + l;
             sPbg[e] = (g < N) ? P[(size_t)(EKF_BASE + 3 * g + w % 3) * ld + 7 + w / 3] : 0.f;
             sPfb[e] = (f < N) ? P[(size_t)(7 + w % 9) * ld + EKF_BASE + 3 * f + w / 9] : 0.f;
-            sBf[e] = (f < N) ? FB[(size_t)f * 27 + w] : 0.f;
-            sBg[e] = (g < N) ? FB[(size_t)g * 27 + w] : 0.f;
+            if (!LIN) {
+                sBf[e] = (f < N) ? FB[(size_t)f * 27 + w] : 0.f;
+                sBg[e] = (g < N) ? FB[(size_t)g * 27 + w] : 0.f;
+            }
         }
-        for (int e = tid; e < PT * 9; e += 256) {
-            const int l = e / 9, w = e % 9;
-            sDf[e] = (f0 + l < N) ? FD[(size_t)(f0 + l) * 9 + w] : 0.f;
-            sDg[e] = (g0 + l < N) ? FD[(size_t)(g0 + l) * 9 + w] : 0.f;
+        if (!LIN) {
+            for (int e = tid; e < PT * 9; e += 256) {
+                const int l = e / 9, w = e % 9;
+                sDf[e] = (f0 + l < N) ? FD[(size_t)(f0 + l) * 9 + w] : 0.f;
+                sDg[e] = (g0 + l < N) ? FD[(size_t)(g0 + l) * 9 + w] : 0.f;
+            }
         }
         __syncthreads();
+        if (LIN) {
+            if (tid < 19) s_bm[tid] = lin_base_motion(s_base, tid, dt);
+            __syncthreads();
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                const int task = tid + 256 * sl;
+                if (task < 384) {
+                    const int side = task >= 192, l = (task % 192) / 12, e = task % 12;
+                    const int lmk = (side ? g0 : f0) + l;
+                    float o[3] = {0.f, 0.f, 0.f};
+                    if (lmk < N) lin_column(s_bm, lu[sl], lv[sl], lrho[sl], e, td, o);
+                    float* dst = (e < 9) ? ((side ? sBg : sBf) + l * 27 + e * 3) : ((side ? sDg : sDf) + l * 9 + (e - 9) * 3);
+                    dst[0] = o[0];
+                    dst[1] = o[1];
+                    dst[2] = o[2];
+                } else if (tI == tJ && tid >= 128 && tid < 128 + PT && f0 + tid - 128 < N) {
+                    // mean propagation with the OLD base state (:102-104)
+                    const V3 o = convolve_feature(s_bm[0], lu[sl], lv[sl], lrho[sl]);
+                    const int lmk = f0 + tid - 128;
+                    mu_next[EKF_BASE + 3 * lmk] = o.x;
+                    mu_next[EKF_BASE + 3 * lmk + 1] = o.y;
+                    mu_next[EKF_BASE + 3 * lmk + 2] = o.z;
+                }
+            }
+            __syncthreads();
+        }
         // X on the base columns, once per landmark row of the tile
         for (int e = tid; e < PT * 27; e += 256) {
             const int l = e / 27, r = (e % 27) / 9, b = e % 9;
@@ -466,7 +590,55 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
     }
     const int wb = (int)blockIdx.x - ntile;
     float* sA = sm;                        // [22*22]  A(i,l) at l*22+i
-    for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) sA[e] = FA[e];
+    float* sLB = sm + 3072;                // LIN: [PC][27] B and [PC][9] D of this workgroup's landmarks
+    float* sLD = sLB + PC * 27;
+    const float* FBp = FB;                 // where this workgroup reads its landmarks' B / D blocks from
+    const float* FDp = FD;
+    int lm0 = 0;                           // ... and the landmark index that corresponds to offset 0 there
+    if (LIN) {
+        float* s_hi = sm + 2048;           // [16][22] convolveBaseState at +delta / -delta
+        float* s_lo = s_hi + 16 * EKF_BASE;
+        lm0 = (wb == 0) ? 0 : ((wb <= chunks) ? (wb - 1) * PC : (wb - chunks - 1) * PC);
+        const int lt = tid - 128;          // threads 128..163: the 36 derivative columns of the PC landmarks
+        float u = 0.f, v = 0.f, rho = 1.f;
+        const bool ltask = wb > 0 && lt >= 0 && lt < PC * 12 && lm0 + lt / 12 < N;
+        if (ltask) {
+            const int lmk = lm0 + lt / 12;
+            u = mu[EKF_BASE + 3 * lmk];
+            v = mu[EKF_BASE + 3 * lmk + 1];
+            rho = mu[EKF_BASE + 3 * lmk + 2];
+        }
+        __syncthreads();                   // s_base
+        if (tid < 32) {
+            lin_base_test_point(s_base, tid, dt, ((tid & 1) ? s_lo : s_hi) + (tid >> 1) * EKF_BASE);
+        } else if (tid == 32 && wb == 0) {
+            float o[EKF_BASE];
+            convolve_base(s_base, dt, o);
+#pragma unroll
+            for (int i = 0; i < EKF_BASE; i++) mu_next[i] = o[i];
+        } else if (tid >= 64 && tid < 64 + 19) {
+            s_bm[tid - 64] = lin_base_motion(s_base, tid - 64, dt);
+        }
+        __syncthreads();
+        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) {
+            const int j = e / EKF_BASE, i = e % EKF_BASE;
+            sA[e] = (j < 16) ? (s_hi[j * EKF_BASE + i] - s_lo[j * EKF_BASE + i]) / td : ((i == j) ? 1.f : 0.f);
+        }
+        if (wb > 0 && lt >= 0 && lt < PC * 12) {
+            float o[3] = {0.f, 0.f, 0.f};
+            const int l = lt / 12, e = lt % 12;
+            if (ltask) lin_column(s_bm, u, v, rho, e, td, o);
+            float* dst = (e < 9) ? (sLB + l * 27 + e * 3) : (sLD + l * 9 + (e - 9) * 3);
+            dst[0] = o[0];
+            dst[1] = o[1];
+            dst[2] = o[2];
+        }
+        FBp = sLB;
+        FDp = sLD;
+        __syncthreads();  // A and the landmarks' B, D blocks are in LDS
+    } else {
+        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) sA[e] = FA[e];
+    }
     if (wb <= chunks) {
         // ---- base rows: i < 22; columns j < 22 (wb == 0) or the 63 columns of landmark chunk wb-1 ----
         float* sX1 = sm + 512;             // [22][22]  X(i,k), k < 22, at k*22+i
@@ -502,8 +674,8 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         for (int e = tid; e < EKF_BASE * ncol; e += 256) {
             const int i = e % EKF_BASE, jc = e / EKF_BASE;
             const int g = g0 + jc / 3, sIdx = jc % 3, j = j0 + jc;
-            const float* b = FB + (size_t)g * 27 + sIdx;
-            const float* d = FD + (size_t)g * 9 + sIdx;
+            const float* b = FBp + (size_t)(g - lm0) * 27 + sIdx;
+            const float* d = FDp + (size_t)(g - lm0) * 9 + sIdx;
             float acc = 0.f;
             for (int c = 0; c < 9; c++) acc = acc + sX1[(7 + c) * EKF_BASE + i] * b[c * 3];
             for (int q = 0; q < 3; q++) acc = acc + sX2[(3 * (jc / 3) + q) * EKF_BASE + i] * d[q * 3];
@@ -520,8 +692,8 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
             const int ic = e % nrow, k = e / nrow;
             const int f = f0 + ic / 3, r = ic % 3;
             const float* pc = P + (size_t)k * ld;
-            const float* b = FB + (size_t)f * 27 + r;
-            const float* d = FD + (size_t)f * 9 + r;
+            const float* b = FBp + (size_t)(f - lm0) * 27 + r;
+            const float* d = FDp + (size_t)(f - lm0) * 9 + r;
             float acc = 0.f;
             for (int c = 0; c < 9; c++) acc = acc + b[c * 3] * pc[7 + c];
             for (int q = 0; q < 3; q++) acc = acc + d[q * 3] * pc[EKF_BASE + 3 * f + q];
@@ -667,7 +839,10 @@ void launch_build_dense_F(ekfvio_filter* f, float* Fdense) {
 
 // process(dt) (:96-121)
 void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
-    launch_linearize(f, dt, book);
+    // structured mode linearises inside the propagation kernel (predict_fused_kernel<true>); the dense mode and
+    // ekfvio_linearize keep the stand-alone linearize_kernel
+    const bool lin_in_predict = f->cfg.predict_mode != EKFVIO_PREDICT_DENSE && f->fuse_linearize;
+    if (!lin_in_predict) launch_linearize(f, dt, book);
     const int n = f->n, ld = f->ldp;
     dim3 grid((n + 255) / 256, n);
     if (f->cfg.predict_mode == EKFVIO_PREDICT_DENSE) {
@@ -685,8 +860,14 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
         ProfScope ps(f, PC_PREDICT, 4.0 * n * (358.0 + 36.0 * f->N));
         const int ts = (f->N + PT - 1) / PT;
         const int chunks = (f->N + PC - 1) / PC;
-        hipLaunchKernelGGL(predict_fused_kernel, dim3(ts * ts + 1 + 2 * chunks), dim3(256), 0, f->stream, f->P, ld, f->N, n,
-                           f->FA, f->FB, f->FD, dt, f->P2, ts, chunks);
+        BookArgs b;
+        if (book && lin_in_predict) b = *book;
+        if (lin_in_predict)
+            hipLaunchKernelGGL(predict_fused_kernel<true>, dim3(ts * ts + 1 + 2 * chunks + (b.enabled ? 1 : 0)), dim3(256), 0, f->stream,
+                               f->P, ld, f->N, n, f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b);
+        else
+            hipLaunchKernelGGL(predict_fused_kernel<false>, dim3(ts * ts + 1 + 2 * chunks), dim3(256), 0, f->stream, f->P, ld, f->N, n,
+                               f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b);
         std::swap(f->P, f->P2);  // out of place; P2's padding is zero as well (never written outside n x n)
     }
     // the propagated mean becomes the state (landmarks used the OLD base state, :102-107)
