@@ -106,6 +106,8 @@ struct ekfvio_filter {
     float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
     int* info = nullptr;       // [4] device flags: [0] non-positive pivot seen
     int* h_info = nullptr;     // pinned host mirror
+    unsigned char* h_meas = nullptr;  // pinned staging for one frame's (z, R, pass): one H2D copy per ekfvio_update
+    unsigned char* d_meas = nullptr;  // its device image: z at 0, R at 8N_cap, pass at 24N_cap bytes
     // uploaded measurement sequences
     float* seq_z = nullptr;
     float* seq_R = nullptr;
