@@ -466,3 +466,36 @@ def test_persistent_sweep_matches_per_step_sweep(monkeypatch):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     for key in ("base_mu", "feat_mu", "Sigma"):
         assert np.array_equal(res[0][2][key], res[1][2][key]), key
+
+
+def test_launch_fusion_knobs_do_not_change_bits(monkeypatch):
+    """EKFVIO_FUSE_GATHER / EKFVIO_FUSE_LINEARIZE only choose how the same device functions are spread over launches
+    (gather + first diagonal tile in one launch; the Jacobian blocks formed inside the propagation kernel): every
+    combination must leave identical bits in the state, through the per-call API and through graph replay."""
+    N = 40
+    sc = Scenario(N, seed=5)
+    fr = list(sc.frames(6))
+    ref = None
+    for fg in ("1", "0"):
+        for fl in ("1", "0"):
+            monkeypatch.setenv("EKFVIO_FUSE_GATHER", fg)
+            monkeypatch.setenv("EKFVIO_FUSE_LINEARIZE", fl)
+            states = []
+            for replay in (False, True):
+                g = TightlyCoupledEKF(max_features=N)
+                g.addNewFeatures(sc.initial_features())
+                if replay:
+                    g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+                    g.run_uploaded(0, len(fr), sc.dt)
+                    g.synchronize()
+                else:
+                    for z, R, p in fr:
+                        g.process(sc.dt)
+                        assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
+                states.append(g.get_state())
+                g.close()
+            for st in states:
+                if ref is None:
+                    ref = st
+                for key in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"):
+                    assert np.array_equal(st[key], ref[key]), (fg, fl, key)
