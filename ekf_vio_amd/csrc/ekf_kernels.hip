@@ -841,7 +841,10 @@ void launch_build_dense_F(ekfvio_filter* f, float* Fdense) {
 void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
     // structured mode linearises inside the propagation kernel (predict_fused_kernel<true>); the dense mode and
     // ekfvio_linearize keep the stand-alone linearize_kernel
-    const bool lin_in_predict = f->cfg.predict_mode != EKFVIO_PREDICT_DENSE && f->fuse_linearize;
+    // (while the landmark tiles are a few rounds of workgroups: with thousands of tiles, N = 1024, the Jacobian blocks
+    // formed 2 * 64 times over cost more than the launch they save)
+    const int tiles_side = (f->N + PT - 1) / PT;
+    const bool lin_in_predict = f->cfg.predict_mode != EKFVIO_PREDICT_DENSE && f->fuse_linearize && tiles_side * tiles_side <= 4 * f->num_cus;
     if (!lin_in_predict) launch_linearize(f, dt, book);
     const int n = f->n, ld = f->ldp;
     dim3 grid((n + 255) / 256, n);
