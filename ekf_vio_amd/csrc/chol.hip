@@ -263,8 +263,11 @@ __device__ __forceinline__ void potrf_tile_update(float* A, int c0, int ti, int 
     const int li = lane & 15, lk = lane >> 4;
     const int rb = c0 + 16 + 16 * ti, cb = c0 + 16 + 16 * tj;
     const f32x4 u = mma16(A + c0 * PLD + rb, 1, PLD, A + c0 * PLD + cb, 1, PLD, lane);
+    float t[4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) A[(cb + 4 * lk + g) * PLD + rb + li] -= u[g];
+    for (int g = 0; g < 4; g++) t[g] = A[(cb + 4 * lk + g) * PLD + rb + li];  // all reads before the first write (see chol_step_kernel)
+#pragma unroll
+    for (int g = 0; g < 4; g++) A[(cb + 4 * lk + g) * PLD + rb + li] = t[g] - u[g];
 }
 
 // Inverse of the 16x16 diagonal block b by forward substitution in registers: lane r (< 16)
@@ -543,15 +546,41 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
     // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
     const float* Bj = (i != j) ? Tj : Ti;
-    const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
     float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
     const int r = wr * 32 + (lane & 31);
-    if (i == k + 1 && j == k + 1) {
-        // next diagonal tile: update into LDS and factor it now (look-ahead)
+    const bool chain = (i == k + 1 && j == k + 1);
+#ifndef EKF_CHOL_LATE_TARGET
+    // The chain workgroup requests its target tile BEFORE the 64^3 product and waits for it AFTER: the memory round
+    // trip runs under the MFMA stream.  The compiler cannot express that (it waits for a load before the first use it
+    // can see, and a register pin is such a use), so the loads are inline asm, which its s_waitcnt insertion does not
+    // track, and the wait is written by hand.  (Its own vmcnt waits stay correct: the counter retires in order, extra
+    // outstanding loads only make them wait longer.)
+    float tgt[16];
+    if (chain) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float* src = Sij + (size_t)c * lds + r;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(tgt[q]) : "v"(src) : "memory");
+        }
+    }
+#endif
+    const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
+    if (chain) {
+        // next diagonal tile: update into LDS and factor it now (look-ahead)
+#ifndef EKF_CHOL_LATE_TARGET
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 16; q++) asm volatile("" : "+v"(tgt[q]));  // uses stay behind the wait
+#endif
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+#ifndef EKF_CHOL_LATE_TARGET
+            Tl[c * PLD + r] = tgt[q] - up[q];
+#else
             Tl[c * PLD + r] = Sij[(size_t)c * lds + r] - up[q];
+#endif
         }
         __syncthreads();
         CSTAMP(3);
@@ -562,10 +591,18 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         if (bad && tid == 0) atomicOr(info, 1);
         CSTAMP(5);
     } else {
+        // read all sixteen targets, then write them: written as sixteen `-=` the compiler cannot rule out that a store
+        // aliases the next load (the stride lds is a run-time value) and serialises sixteen memory round trips
+        float t[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            Sij[(size_t)c * lds + r] -= up[q];
+            t[q] = Sij[(size_t)c * lds + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            Sij[(size_t)c * lds + r] = t[q] - up[q];
         }
     }
 }
