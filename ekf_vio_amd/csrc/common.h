@@ -15,7 +15,9 @@
 #ifndef EKF_POTRF_FV
 #define EKF_POTRF_FV 8        // factor-phase variant of potrf64_lds (chol.hip): 8 = generated hand-scheduled chain
 #endif
+#ifndef EKF_SWEEP_SPLIT_MB
 #define EKF_SWEEP_SPLIT_MB 16  // from this many 64-wide block steps on, the sweep solves each panel block once (chol.hip)
+#endif
 #define EKF_FLUSH_THRESH (1e-8f * 1e-5f)
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
