@@ -506,7 +506,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     CSTAMP(0);
     __shared__ float Ti[PB * PLD];   // A_ik, then L_ik
     __shared__ float Tj[PB * PLD];   // A_jk, then L_jk
-    __shared__ float Tl[PB * PLD];   // L_kk, later the updated next diagonal tile
+    // L_kk, later the updated next diagonal tile.  Without the in-kernel panel solves (SOLVE = false) only the chain
+    // workgroup needs it, and that one has i == j and leaves Tj unused: sharing its storage brings the kernel from 54
+    // to 38 KB of LDS, four resident workgroups per compute unit instead of two for the thousands of tiles of a step.
+    __shared__ float Tl_own[SOLVE ? PB * PLD : 1];
+    float* Tl = SOLVE ? Tl_own : Tj;
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
