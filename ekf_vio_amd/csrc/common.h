@@ -13,7 +13,7 @@
 #define EKF_TILE 64  // block size of every blocked algorithm (GEMM tile edge, Cholesky nb)
 // prune(SPARSE_THRESH, SPARSE_EPS) keeps |x| > 1e-8f*1e-5f (TightlyCoupledEKF.h:13-14, .cpp:117,580,591,625)
 #ifndef EKF_POTRF_FV
-#define EKF_POTRF_FV 8        // factor-phase variant of potrf64_lds (chol.hip): 8 = generated hand-scheduled chain
+#define EKF_POTRF_FV 10       // factor-phase variant of potrf64_lds (chol.hip): 10 = generated stream incl. its LDS traffic, 8 = without, 0 = plain
 #endif
 #ifndef EKF_SWEEP_SPLIT_MB
 #define EKF_SWEEP_SPLIT_MB 16  // from this many 64-wide block steps on, the sweep solves each panel block once (chol.hip)

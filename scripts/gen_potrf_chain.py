@@ -60,6 +60,61 @@ def gen(nowait=False, nofill=False):
     return out
 
 
+def gen_ls(pld=65):
+    """The stream of gen() with the panel's LDS traffic inside it: the sixteen column loads are issued at the top and
+    the chain starts as soon as the first two have landed; column k is written back right after its scale (every lane
+    to its own address `sb`, advanced by the per-lane stride `ss` after each column: a matrix column for the lanes of
+    the panel, a row of the 16x16 inverse for the identity lanes), so nothing but the last write's latency remains
+    behind the chain.  The strict upper triangle of the diagonal block is stored as it comes out of the sweep (stale
+    values): nothing in LDS reads it and the global stores drop it."""
+    out = []
+    emit = out.append
+    for j in range(16):
+        emit("ds_read_b32 %%[a%d], %%[lb] offset:%d" % (j, 4 * pld * j))
+    for k in range(16):
+        ak = "%%[a%d]" % k
+        queue = list(range(k + 1, 16)) if k >= 1 else []
+        dprev = "%%[d%d]" % ((k - 1) % 2)
+        aprev = "%%[a%d]" % (k - 1)
+
+        def fill(n):
+            took = 0
+            while took < n and queue:
+                j = queue.pop(0)
+                emit("v_fmac_f32_dpp %%[a%d], -%s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf" % (j, dprev, aprev, j))
+                took += 1
+            if took < n:
+                emit("s_nop %d" % (n - took - 1))
+
+        emit("; column %d" % k)
+        if k == 0:
+            emit("s_waitcnt lgkmcnt(14)")                     # a0 and a1 have landed
+        emit("v_max_f32 %%[t], 0x1e3ce508, %s" % ak)
+        if k == 1:
+            emit("s_waitcnt lgkmcnt(0)")                      # the other columns, column 0's write and bpermute
+        elif queue:
+            emit("s_waitcnt lgkmcnt(0)")
+        fill(1)
+        emit("v_readlane_b32 %%[s], %%[t], %%[c0]+%d" % k)
+        fill(2)
+        emit("v_rsq_f32 %[t], %[s]")
+        fill(1)
+        emit("v_mul_f32 %s, %s, %%[t]" % (ak, ak))
+        emit("ds_write_b32 %%[sb], %s" % ak)
+        if k <= 14:
+            if k <= 13:
+                emit("ds_bpermute_b32 %%[d%d], %%[addr], %s" % (k % 2, ak))
+            emit("v_readlane_b32 %%[s], %s, %%[c0]+%d" % (ak, k + 1))
+            emit("v_add_u32 %[sb], %[ss], %[sb]")
+            fill(1)
+            emit("v_fma_f32 %%[a%d], -%s, %%[s], %%[a%d]" % (k + 1, ak, k + 1))
+            while queue:
+                fill(1)
+        assert not queue
+    emit("s_waitcnt lgkmcnt(0)")                              # the compiler does not see these LDS writes
+    return out
+
+
 def main():
     w = sys.stdout.write
     if len(sys.argv) > 1 and sys.argv[1] == "--experiments":  # timing-only variants (wrong results)
@@ -84,6 +139,20 @@ def main():
     w("        : " + ", ".join('[a%d] "+v"(a[%d])' % (i, i) for i in range(16)) + ",\n")
     w('          [d0] "=&v"(d0), [d1] "=&v"(d1), [t] "=&v"(t), [s] "=&s"(s)\n')
     w('        : [addr] "v"(diag_lane4), [c0] "n"(C0));\n')
+    w("}\n\n")
+    w("// The same stream with the panel's LDS loads and stores inside it (see gen_ls in the generator).  lb: LDS byte address\n")
+    w("// of this lane's element of the panel's first column; sb / ss: where this lane writes column 0 and by how many bytes\n")
+    w("// that address advances per column.\n")
+    w("template <int C0>\n")
+    w("__device__ __forceinline__ void potrf_panel16_chain_ls(unsigned lb, unsigned sb, unsigned ss, int diag_lane4) {\n")
+    w("    float " + ", ".join("a%d" % i for i in range(16)) + ", d0, d1, t, s;\n")
+    w("    asm volatile(\n")
+    for ln in gen_ls():
+        w('        "%s\\n\\t"\n' % ln)
+    w("        : " + ", ".join('[a%d] "=&v"(a%d)' % (i, i) for i in range(16)) + ",\n")
+    w('          [d0] "=&v"(d0), [d1] "=&v"(d1), [t] "=&v"(t), [s] "=&s"(s), [sb] "+v"(sb)\n')
+    w('        : [addr] "v"(diag_lane4), [c0] "n"(C0), [lb] "v"(lb), [ss] "v"(ss)\n')
+    w('        : "memory");\n')
     w("}\n")
 
 
