@@ -569,15 +569,19 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     // outstanding loads only make them wait longer.)
     float tgt[16];
     if (chain) {
+        // scalar base + 32-bit lane offset + a scalar step per element: one VALU add per load instead of a 64-bit
+        // multiply-add chain (the tile spans at most 64 * lds floats: the offsets fit 32 bits)
+        const unsigned off0 = ((unsigned)(wc * 32 + 4 * (lane >> 5)) * (unsigned)lds + (unsigned)r) * 4u;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const float* src = Sij + (size_t)c * lds + r;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(tgt[q]) : "v"(src) : "memory");
+            const unsigned off = off0 + (unsigned)((q & 3) + 8 * (q >> 2)) * (unsigned)lds * 4u;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(tgt[q]) : "v"(off), "s"(Sij) : "memory");
         }
     }
 #endif
+    CSTAMP(7);
     const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
+    CSTAMP(6);
     if (chain) {
         // next diagonal tile: update into LDS and factor it now (look-ahead)
 #ifndef EKF_CHOL_LATE_TARGET

@@ -20,6 +20,10 @@ for k in range((2 * N + 63) // 64 - 1):
     print("step %2d: " % k + "  ".join("%s %6d" % (names[i], v[b + i + 1] - v[b + i]) for i in range(5)) + "   | in-kernel total %6d cycles = %.2f us at 2.4 GHz" % (v[b + 5] - v[b], (v[b + 5] - v[b]) / 2400.0))
 
 for k in range((2 * N + 63) // 64 - 1):
+    b = 32 + 8 * k
+    if v[b + 6]:
+        print("step %2d rank-64 update: L_ik store + target requests %5d, product issued over %5d, target tile -> LDS + barrier %5d" % (k, v[b + 7] - v[b + 2], v[b + 6] - v[b + 7], v[b + 3] - v[b + 6]))
+for k in range((2 * N + 63) // 64 - 1):
     b = 960 + 4 * k
     print("step %2d panel solve (wave 0): operand preload %5d  MFMA chain %5d  write-back %5d" % (k, v[b + 1] - v[b], v[b + 2] - v[b + 1], v[b + 3] - v[b + 2]))
 
