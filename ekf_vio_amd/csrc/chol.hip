@@ -35,7 +35,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PB 64
-#define PLD 65  // LDS tile stride: element (r,c) of a tile lives at c*PLD + r  (column-major)
+#ifndef PLD
+#define PLD 68  // LDS tile stride: element (r,c) of a tile lives at c*PLD + r  (column-major); a multiple of 4 keeps
+                // 16-byte LDS accesses aligned (tile movers), 68 = 4 mod 32 spreads the columns over the banks
+#endif
 #define ILD 17  // stride of a 16x16 inverse block in LDS
 #define INV_LDS (4 * 16 * ILD)
 
@@ -80,7 +83,11 @@ __device__ __forceinline__ void load_tile(float* T, const float* __restrict__ G,
         const int c = e >> 4, r4 = (e & 15) * 4;
         const float4 v = *reinterpret_cast<const float4*>(G + (size_t)c * ld + r4);
         float* t = T + c * PLD + r4;
+#if PLD % 4 == 0
+        *reinterpret_cast<float4*>(t) = v;  // one ds_write_b128
+#else
         t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+#endif
     }
 }
 __device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G, int ld, int tid) {
@@ -89,7 +96,11 @@ __device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G
         const int e = tid + it * 256;
         const int c = e >> 4, r4 = (e & 15) * 4;
         const float* t = T + c * PLD + r4;
+#if PLD % 4 == 0
+        *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) = *reinterpret_cast<const float4*>(t);
+#else
         *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) = make_float4(t[0], t[1], t[2], t[3]);
+#endif
     }
 }
 // lower triangle of a diagonal tile; the strict upper triangle is written as zero
@@ -99,8 +110,14 @@ __device__ __forceinline__ void store_tile_lower(const float* T, float* __restri
         const int e = tid + it * 256;
         const int c = e >> 4, r4 = (e & 15) * 4;
         const float* t = T + c * PLD + r4;
+#if PLD % 4 == 0
+        const float4 q = *reinterpret_cast<const float4*>(t);
+        *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) =
+            make_float4(r4 >= c ? q.x : 0.f, r4 + 1 >= c ? q.y : 0.f, r4 + 2 >= c ? q.z : 0.f, r4 + 3 >= c ? q.w : 0.f);
+#else
         *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) =
             make_float4(r4 >= c ? t[0] : 0.f, r4 + 1 >= c ? t[1] : 0.f, r4 + 2 >= c ? t[2] : 0.f, r4 + 3 >= c ? t[3] : 0.f);
+#endif
     }
 }
 // four 16x16 inverse blocks (global: block p at p*256, column-major ld 16) <-> LDS (stride ILD)
@@ -406,7 +423,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
 template <int FV>
 __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
                                                             int ldl, float* __restrict__ Linv, long long* stamps) {
-    __shared__ float A[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float A[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x;
     if (tid == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime();
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restr
 // Factor the first diagonal block (step "-1" of the sweep).
 __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
                                                       int ldl, float* __restrict__ Linv, int* info) {
-    __shared__ float A[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float A[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x;
     load_tile(A, S, lds, tid);
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
 // unit's LDS per workgroup (EKF_GATHER_POTRF_LDS): one workgroup per compute unit, the chain has its own.
 __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float* __restrict__ L, int ldl, float* __restrict__ Linv,
                                                            int* info, long long* dbg) {
-    extern __shared__ float dyn_lds[];
+    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
     const int tid = threadIdx.x;
 #define GSTAMP_(slot)                                                                               \
     do {                                                                                            \
@@ -512,12 +529,12 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[32 + 8 * k + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
     CSTAMP(0);
-    __shared__ float Ti[PB * PLD];   // A_ik, then L_ik
-    __shared__ float Tj[PB * PLD];   // A_jk, then L_jk
+    __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];   // A_ik, then L_ik
+    __shared__ __attribute__((aligned(16))) float Tj[PB * PLD];   // A_jk, then L_jk
     // L_kk, later the updated next diagonal tile.  Without the in-kernel panel solves (SOLVE = false) only the chain
     // workgroup needs it, and that one has i == j and leaves Tj unused: sharing its storage brings the kernel from 54
     // to 38 KB of LDS, four resident workgroups per compute unit instead of two for the thousands of tiles of a step.
-    __shared__ float Tl_own[SOLVE ? PB * PLD : 1];
+    __shared__ __attribute__((aligned(16))) float Tl_own[SOLVE ? PB * PLD : 1];
     float* Tl = SOLVE ? Tl_own : Tj;
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -627,8 +644,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
 // them; na = 0 for the last block column) and the extra row blocks (X, I).
 __global__ __launch_bounds__(256) void chol_panel_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
                                                          int ldl, const float* __restrict__ Linv, int k, int mb, int na, int idb0) {
-    __shared__ float Ti[PB * PLD];
-    __shared__ float Tl[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float Tl[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -749,9 +766,9 @@ __device__ __forceinline__ void sweep_signal_add(int* flag, int tid) {
 __global__ __launch_bounds__(256) void chol_sweep_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
                                                          float* __restrict__ Linv, int mb, int rb, int idb0, int* info,
                                                          int* sync, long long* dbg) {
-    __shared__ float Ti[PB * PLD];
-    __shared__ float Tj[PB * PLD];
-    __shared__ float Tl[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float Tj[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float Tl[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;

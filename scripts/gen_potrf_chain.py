@@ -60,7 +60,7 @@ def gen(nowait=False, nofill=False):
     return out
 
 
-def gen_ls(pld=65):
+def gen_ls():
     """The stream of gen() with the panel's LDS traffic inside it: the sixteen column loads are issued at the top and
     the chain starts as soon as the first two have landed; column k is written back right after its scale (every lane
     to its own address `sb`, advanced by the per-lane stride `ss` after each column: a matrix column for the lanes of
@@ -70,7 +70,7 @@ def gen_ls(pld=65):
     out = []
     emit = out.append
     for j in range(16):
-        emit("ds_read_b32 %%[a%d], %%[lb] offset:%d" % (j, 4 * pld * j))
+        emit("ds_read_b32 %%[a%d], %%[lb] offset:%%[p4]*%d" % (j, j))      # p4 = 4 * PLD: the byte stride of a tile column
     for k in range(16):
         ak = "%%[a%d]" % k
         queue = list(range(k + 1, 16)) if k >= 1 else []
@@ -151,7 +151,7 @@ def main():
         w('        "%s\\n\\t"\n' % ln)
     w("        : " + ", ".join('[a%d] "=&v"(a%d)' % (i, i) for i in range(16)) + ",\n")
     w('          [d0] "=&v"(d0), [d1] "=&v"(d1), [t] "=&v"(t), [s] "=&s"(s), [sb] "+v"(sb)\n')
-    w('        : [addr] "v"(diag_lane4), [c0] "n"(C0), [lb] "v"(lb), [ss] "v"(ss)\n')
+    w('        : [addr] "v"(diag_lane4), [c0] "n"(C0), [lb] "v"(lb), [ss] "v"(ss), [p4] "n"(4 * PLD)\n')
     w('        : "memory");\n')
     w("}\n")
 
