@@ -188,6 +188,19 @@ def main():
             extra["roofline"]["traffic"] = pj["p_update_gemm_traffic_bytes_per_launch"]
             extra["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)"
             extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
+        # The same GEMM kernel family at the N=1024 stress shape (3094 x 3094 x 2048), where a launch is many rounds of
+        # workgroups instead of one: what the kernel reaches when the shape lets it (the N=256 figure above is bounded
+        # by one workgroup's latency plus the kernel boundary)
+        try:
+            import ctypes as C
+            us = C.c_double(0)
+            if g.lib.ekfvio_test_gemm_bench(g.h, 1, 0, 3094, 3094, 2048, 20, 0, C.byref(us)) == 0 and us.value > 0:
+                tf = 2.0 * 3094 * 3094 * 2048 / (us.value * 1e-6) / 1e12
+                extra["roofline_stress_shape"] = {"shape": {"M": 3094, "N": 3094, "K": 2048}, "avg_launch_us": us.value,
+                                                  "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": tf / PEAK_F32_MFMA_TFLOPS, "note": "plain C = A*B^T of the N=1024 Joseph shape, 20 launches"}
+        except Exception as ex:  # diagnostic extra, never fatal
+            extra["roofline_stress_shape"] = {"error": str(ex)}
         # PCIe-inclusive rate (never `value`): the per-call boundary with host-resident measurements,
         # one ekfvio_process + one synchronising ekfvio_update per step
         nh = min(100, len(fr))
