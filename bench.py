@@ -147,6 +147,7 @@ def main():
     fr = list(sc.frames(n_frames))
     g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
     dt = sc.dt
+    g.run_uploaded(0, 0, dt)  # captures the launch graphs (nothing runs): never inside the timed region, whatever W is
     g.run_uploaded(0, args.warmup, dt)
     g.synchronize()
     torch.cuda.synchronize()

@@ -145,7 +145,9 @@ struct ekfvio_filter {
 
     // --- hipGraph replay of device-resident sequences (an even number of steps per graph: the mean
     //     ping-pong mu <-> mu_next is back in its starting orientation after an even count) ---
-    hipGraphExec_t step_graph = nullptr;
+    hipGraphExec_t step_graph = nullptr;      // EKF_GRAPH_STEPS filter steps
+    hipGraphExec_t step_graph_big = nullptr;  // EKF_GRAPH_STEPS_BIG filter steps (long runs: fewer graph launches)
+    hipGraphExec_t step_graph_pair = nullptr; // 2 filter steps (tails and short runs)
     int graph_N = -1, graph_m = -1, graph_frames = -1;
     float graph_dt = -1.f;
     float* graph_mu = nullptr;      // orientation of the mean / covariance ping-pong at capture time

@@ -174,7 +174,8 @@ int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float 
 int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z, const float* R, const uint8_t* pass);
 /* Runs process(dt) + update(frame i) for i = first .. first+count-1 (indices wrap modulo the
  * uploaded frame count) with no host<->device traffic.  Asynchronous; pair with
- * ekfvio_synchronize. */
+ * ekfvio_synchronize.  count = 0 runs nothing but prepares the launch graphs the runs replay (their
+ * capture costs milliseconds: a caller that times a run prepares first). */
 int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt);
 int ekfvio_synchronize(ekfvio_filter* f);
 
