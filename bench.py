@@ -189,6 +189,15 @@ def main():
             extra["roofline"]["traffic"] = pj["p_update_gemm_traffic_bytes_per_launch"]
             extra["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)"
             extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
+        # PCIe-inclusive rate (never `value`): the per-call boundary with host-resident measurements,
+        # one ekfvio_process + one synchronising ekfvio_update per step
+        nh = min(100, len(fr))
+        th = time.perf_counter()
+        for z_h, R_h, p_h in fr[:nh]:
+            g.process(dt)
+            g.updateWithFeaturePositions(z_h, R_h, p_h)
+        g.synchronize()
+        extra["pcie_inclusive_steps_per_s"] = nh / (time.perf_counter() - th)
         # The same GEMM kernel family at the N=1024 stress shape (3094 x 3094 x 2048), where a launch is many rounds of
         # workgroups instead of one: what the kernel reaches when the shape lets it (the N=256 figure above is bounded
         # by one workgroup's latency plus the kernel boundary)
@@ -202,15 +211,6 @@ def main():
                                                   "frac": tf / PEAK_F32_MFMA_TFLOPS, "note": "plain C = A*B^T of the N=1024 Joseph shape, 20 launches"}
         except Exception as ex:  # diagnostic extra, never fatal
             extra["roofline_stress_shape"] = {"error": str(ex)}
-        # PCIe-inclusive rate (never `value`): the per-call boundary with host-resident measurements,
-        # one ekfvio_process + one synchronising ekfvio_update per step
-        nh = min(100, len(fr))
-        th = time.perf_counter()
-        for z_h, R_h, p_h in fr[:nh]:
-            g.process(dt)
-            g.updateWithFeaturePositions(z_h, R_h, p_h)
-        g.synchronize()
-        extra["pcie_inclusive_steps_per_s"] = nh / (time.perf_counter() - th)
         extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps or max(3, int(round(60.0 * (256.0 / N) ** 3)))
