@@ -499,6 +499,36 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
                 }
             }
         }
+#ifndef EKF_PREDICT_LIN_TWO_BARRIERS
+        if (LIN) {
+            // the staged operands are requested first; while they fly, 19 threads of the last wavefront form the base
+            // motions from the base state read straight from global memory (no LDS hop, no extra barrier)
+            float pg[2], pf[2];
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int e = tid + 256 * it;
+                const int l = e / 27, w = e % 27;
+                const int f = f0 + l, g = g0 + l;
+                const bool in = e < PT * 27;
+                pg[it] = (in && g < N) ? P[(size_t)(EKF_BASE + 3 * g + w % 3) * ld + 7 + w / 3] : 0.f;
+                pf[it] = (in && f < N) ? P[(size_t)(7 + w % 9) * ld + EKF_BASE + 3 * f + w / 9] : 0.f;
+            }
+            if (tid >= 192 && tid < 192 + 19) {
+                float b[EKF_BASE];
+#pragma unroll
+                for (int i = 0; i < EKF_BASE; i++) b[i] = mu[i];
+                s_bm[tid - 192] = lin_base_motion(b, tid - 192, dt);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int e = tid + 256 * it;
+                if (e < PT * 27) {
+                    sPbg[e] = pg[it];
+                    sPfb[e] = pf[it];
+                }
+            }
+        } else
+#endif
         for (int e = tid; e < PT * 27; e += 256) {
             const int l = e / 27, w = e % 27;
             const int f = f0 + l, g = g0 + l;
@@ -518,8 +548,10 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         }
         __syncthreads();
         if (LIN) {
+#ifdef EKF_PREDICT_LIN_TWO_BARRIERS
             if (tid < 19) s_bm[tid] = lin_base_motion(s_base, tid, dt);
             __syncthreads();
+#endif
 #pragma unroll
             for (int sl = 0; sl < 2; sl++) {
                 const int task = tid + 256 * sl;
