@@ -36,6 +36,17 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time: the ranks of a multi-GPU launch all come through here at import; whoever gets the lock
+    # second finds the library fresh and returns
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB_PATH
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     jobs, objs = [], []
