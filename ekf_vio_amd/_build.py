@@ -24,20 +24,34 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+FLAGS_STAMP = os.path.join(LIB_DIR, ".build.flags")
+
+
+def _extra_flags():
+    return os.environ.get("EKFVIO_EXTRA_HIPCC_FLAGS", "").split()  # diagnostics, e.g. -DEKF_GEMM_STAMPS
+
+
+def _flags_key():
+    return " ".join(FLAGS + sorted("%s:%s" % kv for kv in ((k, " ".join(v)) for k, v in FILE_FLAGS.items())) + _extra_flags())
+
+
 def _stale():
-    if not os.path.exists(LIB_PATH):
+    """Only meaningful while holding the build lock (a concurrent builder replaces the library atomically, but the
+    object files and the flags stamp change underneath)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(FLAGS_STAMP):
         return True
+    if open(FLAGS_STAMP).read() != _flags_key():
+        return True  # e.g. a diagnostic build with pricing switches (wrong results) must not survive
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h")]
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB_PATH
+    """Every caller takes the lock, decides staleness under it and links through a temporary name that is renamed
+    into place: the ranks of a multi-GPU launch all come through here at import, and none of them can map a
+    half-written library."""
     os.makedirs(OBJ_DIR, exist_ok=True)
-    # one builder at a time: the ranks of a multi-GPU launch all come through here at import; whoever gets the lock
-    # second finds the library fresh and returns
     import fcntl
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -49,6 +63,8 @@ def build(force=False, verbose=False):
 def _build_locked(force, verbose):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    if not os.path.exists(FLAGS_STAMP) or open(FLAGS_STAMP).read() != _flags_key():
+        force = True  # objects built with other flags
     jobs, objs = [], []
     for src in sources():
         name = os.path.basename(src)
@@ -57,7 +73,7 @@ def _build_locked(force, verbose):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
                 and os.path.getmtime(obj) >= newest_hdr):
             continue
-        extra = os.environ.get("EKFVIO_EXTRA_HIPCC_FLAGS", "").split()  # diagnostics, e.g. -DEKF_GEMM_STAMPS
+        extra = _extra_flags()
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + extra + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
@@ -65,10 +81,15 @@ def _build_locked(force, verbose):
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
+    tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)  # atomic: a concurrent loader maps either the old or the new complete file
+    with open(FLAGS_STAMP + ".tmp", "w") as fh:
+        fh.write(_flags_key())
+    os.replace(FLAGS_STAMP + ".tmp", FLAGS_STAMP)
     return LIB_PATH
 
 

@@ -32,7 +32,8 @@ class EkfvioError(RuntimeError):
 SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_reset", "ekfvio_last_error",
            "ekfvio_add_features", "ekfvio_process", "ekfvio_linearize", "ekfvio_update", "ekfvio_measurement_map",
            "ekfvio_num_features", "ekfvio_dim", "ekfvio_get_base_mu", "ekfvio_get_features", "ekfvio_get_sigma",
-           "ekfvio_get_feature_cov", "ekfvio_get_depth_variance", "ekfvio_check_sigma", "ekfvio_set_state",
+           "ekfvio_get_feature_cov", "ekfvio_get_depth_variance", "ekfvio_set_feature_cov", "ekfvio_metric2pixel_map",
+           "ekfvio_pixel2metric_map", "ekfvio_get_odometry", "ekfvio_get_points", "ekfvio_check_sigma", "ekfvio_set_state",
            "ekfvio_klt_push_frame", "ekfvio_klt_track", "ekfvio_klt_track_points", "ekfvio_klt_get_level",
            "ekfvio_klt_uncertainty_points", "ekfvio_step_image", "ekfvio_replenish", "ekfvio_fast_detect", "ekfvio_test_blurred_level0", "ekfvio_imu",
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
@@ -52,10 +53,10 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB_PATH) or _build._stale():
-        if not build_if_missing:
-            raise FileNotFoundError(_build.LIB_PATH + " not built; run python -m ekf_vio_amd._build")
-        _build.build()  # hipcc cross-compiles gfx950 with or without a GPU present
+    if build_if_missing:
+        _build.build()  # staleness is decided under the build lock; hipcc cross-compiles gfx950 with or without a GPU
+    elif not os.path.exists(_build.LIB_PATH):
+        raise FileNotFoundError(_build.LIB_PATH + " not built; run python -m ekf_vio_amd._build")
     lib = C.CDLL(_build.LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     fp, u8p, ip = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
@@ -68,6 +69,8 @@ def load(build_if_missing=True):
         "ekfvio_num_features": [vp], "ekfvio_dim": [vp], "ekfvio_get_base_mu": [vp, fp],
         "ekfvio_get_features": [vp, fp, fp, u8p], "ekfvio_get_sigma": [vp, fp, i32],
         "ekfvio_get_feature_cov": [vp, i32, fp], "ekfvio_get_depth_variance": [vp, i32, fp],
+        "ekfvio_set_feature_cov": [vp, i32, fp], "ekfvio_metric2pixel_map": [fp, fp], "ekfvio_pixel2metric_map": [fp, fp],
+        "ekfvio_get_odometry": [vp, fp, fp, fp, fp], "ekfvio_get_points": [vp, fp, fp],
         "ekfvio_check_sigma": [vp, fp, fp], "ekfvio_set_state": [vp, i32, fp, fp, fp, u8p, fp, i32],
         "ekfvio_klt_push_frame": [vp, u8p, i32, i32, i32, fp], "ekfvio_klt_track": [vp, fp, fp, u8p],
         "ekfvio_klt_track_points": [vp, fp, fp, i32, fp, u8p],

@@ -110,14 +110,7 @@ int ekfvio_default_config(ekfvio_config* c) {
     return EKFVIO_OK;
 }
 
-int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out) {
-    if (!cfg || !out || cfg->max_features < 0) return EKFVIO_EINVAL;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return EKFVIO_EDEVICE;
-    ekfvio_filter* f = new ekfvio_filter();
-    f->cfg = *cfg;
-    f->device = device;
-    *out = f;
+static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, void* stream) {
     HIPC(f, hipSetDevice(device));
     if (stream) {
         f->stream = (hipStream_t)stream;
@@ -182,10 +175,30 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     return ekfvio_reset(f);
 }
 
+int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out) {
+    if (!out) return EKFVIO_EINVAL;
+    *out = nullptr;
+    if (!cfg || cfg->max_features < 0) return EKFVIO_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return EKFVIO_EDEVICE;
+    ekfvio_filter* f = new ekfvio_filter();
+    f->cfg = *cfg;
+    f->device = device;
+    const int rc = create_body(f, cfg, device, stream);
+    if (rc != EKFVIO_OK) {
+        // a half-built handle never leaves the library: whatever was allocated is released here
+        fprintf(stderr, "ekfvio_create: %s\n", f->last_error.c_str());
+        (void)ekfvio_destroy(f);
+        return rc;
+    }
+    *out = f;
+    return EKFVIO_OK;
+}
+
 int ekfvio_destroy(ekfvio_filter* f) {
     if (!f) return EKFVIO_EINVAL;
-    hipSetDevice(f->device);
-    hipStreamSynchronize(f->stream);
+    (void)hipSetDevice(f->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
     void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
                     f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km, f->sweep_sync, f->sweep_dbg,
                     f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
@@ -204,7 +217,9 @@ int ekfvio_destroy(ekfvio_filter* f) {
     return EKFVIO_OK;
 }
 
-const char* ekfvio_last_error(const ekfvio_filter* f) { return f ? f->last_error.c_str() : "null handle"; }
+const char* ekfvio_last_error(const ekfvio_filter* f) {
+    return f ? f->last_error.c_str() : "null handle (a failed ekfvio_create leaves none behind: its return code says why)";
+}
 
 int ekfvio_reset(ekfvio_filter* f) {
     if (!f) return EKFVIO_EINVAL;
@@ -346,6 +361,46 @@ int ekfvio_get_depth_variance(ekfvio_filter* f, int32_t index, float* var) {
     return EKFVIO_OK;
 }
 
+// setFeatureHomogenousCovariance (TightlyCoupledEKF.cpp:668-676): the four coeffRef writes of the (u,v) block
+int ekfvio_set_feature_cov(ekfvio_filter* f, int32_t index, const float cov[4]) {
+    if (!f || !cov || index < 0 || index >= f->N) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    const int s = EKF_BASE + 3 * index;  // column-major in, column-major block of Sigma out
+    HIPC(f, hipMemcpy2DAsync(f->P + (size_t)s * f->ldp + s, sizeof(float) * f->ldp, cov, sizeof(float) * 2, sizeof(float) * 2, 2,
+                             hipMemcpyHostToDevice, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));  // cov is the caller's memory
+    return EKFVIO_OK;
+}
+
+// getMetric2PixelMap / getPixel2MetricMap (TightlyCoupledEKF.cpp:683-697): J = diag(K(0,0), K(1,1)) and
+// diag(1.0f / K(0,0), 1.0f / K(1,1)) -- proper 2-D indexing of K here (unlike Feature.h:60-66), no state involved.
+int ekfvio_metric2pixel_map(const float K[9], float J[4]) {
+    if (!K || !J) return EKFVIO_EINVAL;
+    J[0] = K[0]; J[1] = 0.f; J[2] = 0.f; J[3] = K[4];
+    return EKFVIO_OK;
+}
+int ekfvio_pixel2metric_map(const float K[9], float J[4]) {
+    if (!K || !J) return EKFVIO_EINVAL;
+    J[0] = 1.0f / K[0]; J[1] = 0.f; J[2] = 0.f; J[3] = 1.0f / K[4];
+    return EKFVIO_OK;
+}
+
+// publishOdometry's payload (EKFVIO.cpp:444-477): the slices of base_mu the message is filled from
+int ekfvio_get_odometry(ekfvio_filter* f, float position[3], float orientation_wxyz[4], float linear[3], float angular[3]) {
+    if (!f) return EKFVIO_EINVAL;
+    float b[EKF_BASE];
+    const int rc = ekfvio_get_base_mu(f, b);
+    if (rc != EKFVIO_OK) return rc;
+    for (int i = 0; i < 3; i++) {
+        if (position) position[i] = b[i];
+        if (linear) linear[i] = b[7 + i];
+        if (angular) angular[i] = b[10 + i];
+    }
+    if (orientation_wxyz)
+        for (int i = 0; i < 4; i++) orientation_wxyz[i] = b[3 + i];
+    return EKFVIO_OK;
+}
+
 int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym) {
     if (!f || !min_diag || !max_asym) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
@@ -389,6 +444,7 @@ int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z,
     if (!f || frames <= 0 || !z || !R || !pass || f->N <= 0) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
     HIPC(f, hipStreamSynchronize(f->stream));
+    drop_graph(f);  // the captured launches hold pointers into the old sequence buffers
     if (f->seq_z) hipFree(f->seq_z);
     if (f->seq_R) hipFree(f->seq_R);
     if (f->seq_pass) hipFree(f->seq_pass);
@@ -466,8 +522,8 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
     if (uniform) {
         const int m = f->seq_m[0];
         int* counter = f->info + 1;
-        f->h_info[1] = first % f->seq_frames;
-        HIPC(f, hipMemcpyAsync(counter, &f->h_info[1], sizeof(int), hipMemcpyHostToDevice, f->stream));
+        // by value (a copy from a host scalar could be overtaken by the next call's write to that scalar)
+        HIPC(f, hipMemsetD32Async((hipDeviceptr_t)counter, first % f->seq_frames, 1, f->stream));
         if (!f->step_graph || f->graph_N != f->N || f->graph_m != m || f->graph_dt != dt || f->graph_mu != f->mu || f->graph_P != f->P ||
             f->graph_seq != f->seq_z || f->graph_frames != f->seq_frames) {
             drop_graph(f);
@@ -508,8 +564,8 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
 int ekfvio_synchronize(ekfvio_filter* f) {
     if (!f) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
-    HIPC(f, hipStreamSynchronize(f->stream));
-    return EKFVIO_OK;
+    // a non-positive pivot met by an asynchronous run (ekfvio_run_uploaded) surfaces here, once
+    return finish_update(f);
 }
 
 // ---- instrumentation ------------------------------------------------------------------
@@ -606,7 +662,7 @@ int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int
     HIPC(f, hipMemcpyAsync(dA, hA.data(), sizeof(float) * hA.size(), hipMemcpyHostToDevice, f->stream));
     HIPC(f, hipMemcpyAsync(dB, hB.data(), sizeof(float) * hB.size(), hipMemcpyHostToDevice, f->stream));
     HIPC(f, hipMemcpyAsync(dC, hC.data(), sizeof(float) * hC.size(), hipMemcpyHostToDevice, f->stream));
-    launch_gemm_variant(f->stream, variant, transB, M, N, Kp, alpha, dA, Mp, dB, brows, beta, dC, Mp, dC, Mp, 0, 0);
+    launch_gemm_variant(f, variant, transB, M, N, Kp, alpha, dA, Mp, dB, brows, beta, dC, Mp, dC, Mp, 0, 0);
     HIPC(f, hipMemcpyAsync(hC.data(), dC, sizeof(float) * hC.size(), hipMemcpyDeviceToHost, f->stream));
     HIPC(f, hipStreamSynchronize(f->stream));
     for (int j = 0; j < N; j++)
@@ -642,10 +698,10 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
     const bool stamped = variant >= 10000;  // library built with -DEKF_GEMM_STAMPS
     variant %= 10000;
     for (int w = 0; w < 3; w++)
-        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
+        launch_gemm_variant(f, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
     HIPC(f, hipEventRecord(f->ev0, f->stream));
     for (int r = 0; r < reps; r++)
-        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
+        launch_gemm_variant(f, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
     HIPC(f, hipEventRecord(f->ev1, f->stream));
     HIPC(f, hipEventSynchronize(f->ev1));
     float ms = 0;
@@ -654,12 +710,12 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
     if (stamped) {  // diagnostic: one stamped launch, stamps returned through mean_us[1..40]
         long long* dst;
         HIPC(f, dev_alloc(f->stream, &dst, 40));
-        gemm_set_stamp_buffer(dst);
-        launch_gemm_variant(f->stream, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
+        f->gemm_stamps = dst;
+        launch_gemm_variant(f, variant, transB, M, N, Kp, -1e-3f, dA, Mp, dB, brows, 1.f, dC, Mp, dC, Mp, 0, lowerB);
         long long hst[40];
         HIPC(f, hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, f->stream));
         HIPC(f, hipStreamSynchronize(f->stream));
-        gemm_set_stamp_buffer(nullptr);
+        f->gemm_stamps = nullptr;
         for (int i = 0; i < 40; i++) mean_us[1 + i] = (double)hst[i];
         hipFree(dst);
     }

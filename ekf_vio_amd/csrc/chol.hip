@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
     GSTAMP_(0);
     float* A = dyn_lds;
     float* Tinv = dyn_lds + PB * PLD;
-    const int m = ga.m;
+    const int m = ga.m_dev ? *ga.m_dev : ga.m;
     // lanes along c: Sigma(idx[c], idx[r]) = P[idx[r]*ld + idx[c]] is (nearly) contiguous in c
     const int c = tid & 63;
     const int sc = (c < m) ? ga.idx[c] : 0;
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
     float v[16], rd[16], ro[16];
 #pragma unroll
     for (int ps = 0; ps < 16; ps++) {
-        const int rc = min((tid >> 6) + 4 * ps, m - 1);
-        ir[ps] = ga.idx[rc];
+        const int rc = max(min((tid >> 6) + 4 * ps, m - 1), 0);  // m may be 0 when it is only known on the device
+        ir[ps] = max(ga.idx[rc], 0);
         rd[ps] = ga.Rm[2 * rc];
         ro[ps] = ga.Rm[2 * rc + 1];
     }
@@ -929,13 +929,14 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
 }
 
 #define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
-void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad) {
+void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
     if (!f->gather_attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   EKF_GATHER_POTRF_LDS);
         f->gather_attr_set = true;
     }
-    const GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+    GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+    if (m_on_device) ga.m_dev = f->info + 2;
     const int nb2 = (m_pad / 64) * (f->ldp / 64);  // 64x64 transposing tiles of Wt
     hipLaunchKernelGGL(gather_potrf_kernel, dim3(1 + ga.nb1 + nb2), dim3(256), EKF_GATHER_POTRF_LDS, f->stream, ga, f->Laug, f->ld_aug,
                        f->Linv, f->info, f->sweep_dbg);
@@ -986,9 +987,9 @@ void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int 
     const float* Lf = Laug;
     const float* Y = Laug + m_pad;
     const float* LinvT = Laug + m_pad + n_pad;
-    launch_gemm(f->stream, 1, n, m_pad, m_pad, 1.f, Y, ld, LinvT, ld, 0.f, nullptr, 0, K, ldk, refine ? 0 : 1, 1);
+    launch_gemm(f, 1, n, m_pad, m_pad, 1.f, Y, ld, LinvT, ld, 0.f, nullptr, 0, K, ldk, refine ? 0 : 1, 1);
     if (refine) {
-        launch_gemm(f->stream, 0, n, m_pad, m_pad, -1.f, K, ldk, Lf, ld, 1.f, Y, ld, scratch, ldk, 0, 1);     // Y - K L
-        launch_gemm(f->stream, 1, n, m_pad, m_pad, 1.f, scratch, ldk, LinvT, ld, 1.f, K, ldk, K, ldk, 1, 1);  // + prune
+        launch_gemm(f, 0, n, m_pad, m_pad, -1.f, K, ldk, Lf, ld, 1.f, Y, ld, scratch, ldk, 0, 1);     // Y - K L
+        launch_gemm(f, 1, n, m_pad, m_pad, 1.f, scratch, ldk, LinvT, ld, 1.f, K, ldk, K, ldk, 1, 1);  // + prune
     }
 }

@@ -103,10 +103,11 @@ struct ekfvio_filter {
     int num_cus = 0;
     int last_m = 0;            // measurement rows of the most recent update (shape of its GEMMs)
     long long* sweep_dbg = nullptr;  // [512] s_memtime stamps of the persistent sweep (diagnostic; null = off)
+    long long* gemm_stamps = nullptr;  // diagnostic stamp buffer handed to the next GEMM launches (null = off)
     float* Km = nullptr;       // [ldp*m_cap]  Sigma H^T, solved in place into the Kalman gain
     float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
     float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
-    int* info = nullptr;       // [4] device flags: [0] non-positive pivot seen
+    int* info = nullptr;       // [4] device words: [0] non-positive pivot seen, [1] frame counter of uploaded sequences, [2] device-side m
     int* h_info = nullptr;     // pinned host mirror
     unsigned char* h_meas = nullptr;  // pinned staging for one frame's (z, R, pass): one H2D copy per ekfvio_update
     unsigned char* d_meas = nullptr;  // its device image: z at 0, R at 8N_cap, pass at 24N_cap bytes
@@ -128,6 +129,7 @@ struct ekfvio_filter {
     uint8_t* klt_status = nullptr; // [max_features]
     float* klt_cov_px = nullptr;   // [4*max_features] sample-based pixel covariances (cfg.sample_based_uncertainty)
     uint8_t* staging = nullptr;    // device staging for the uploaded image
+    uint8_t* h_image = nullptr;    // pinned host staging: the caller's frame is copied here, so its buffer is free on return without a stream sync
     // --- frame ingest + replenishment (fast.hip) ---
     uint8_t* resized = nullptr;    // Frame::Frame's cv::resize output (max image size)
     uint8_t* blurred = nullptr;    // replenishFeatures' cv::GaussianBlur output (only with cfg.fast_blur_sigma != 0)
@@ -184,17 +186,17 @@ struct GemmEpi {
     int n = 0;
     int* frame_counter = nullptr;
     int frames = 0;
+    long long* stamps = nullptr;  // diagnostic s_memtime stamps (library built with -DEKF_GEMM_STAMPS), per handle
 };
-void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+void launch_gemm(ekfvio_filter* f, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                  int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB = 0,
                  const GemmEpi* epi = nullptr);
 
 // same, selecting a tile configuration (0 = production default chosen by shape)
-void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+void launch_gemm_variant(ekfvio_filter* f, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                          int lowerB);
 
-void gemm_set_stamp_buffer(long long* d_buf);  // diagnostics: nullptr disables
 
 // Measurement bookkeeping of one update (device pointers); see bookkeeping_body in ekf_kernels.hip
 struct BookArgs {
@@ -210,13 +212,16 @@ struct BookArgs {
     float* zrow = nullptr;  // measured coordinate per measurement row (f->yres)
     float* Rm = nullptr;
     const int* frame_counter = nullptr;
+    int* m_out = nullptr;   // receives the number of measurement rows 2 * (#passed) (device-side m, ekfvio_step_image)
 };
 BookArgs make_book_args(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, const int* d_frame_counter);
 void launch_linearize(ekfvio_filter* f, float dt, const BookArgs* book = nullptr);
 void launch_build_dense_F(ekfvio_filter* f, float* Fdense);
 void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book = nullptr);
+// m_on_device: the host does not know how many landmarks passed (no D2H of the flags): launches are sized for m = 2N,
+// the kernels read the true row count from f->info[2] (written by the bookkeeping) and treat the rest as padding
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass,
-                   int* d_frame_counter = nullptr, int frames = 0, bool bookkeeping_done = false);
+                   int* d_frame_counter = nullptr, int frames = 0, bool bookkeeping_done = false, bool m_on_device = false);
 void launch_check_sigma(ekfvio_filter* f, float* d_out);
 // klt.hip helpers shared with fast.hip
 int klt_level_pitch(int w);
@@ -235,7 +240,7 @@ void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);
 // m_pad x m_pad, X has n_pad rows) -> Laug = [L; X L^-T; L^-T], both ld x m_pad column-major.
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld,
                        bool first_tile_done = false);
-void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad);
+void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false);
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);
 // K = X A^-1 (n rows, ldk) from the sweep output: K = Y L^-1 (+ optional residual refinement).
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,

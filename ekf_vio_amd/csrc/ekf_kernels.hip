@@ -210,6 +210,7 @@ __device__ __forceinline__ void bookkeeping_body(const BookArgs& a) {
     }
     __syncthreads();
     const int m = 2 * s_total;
+    if (tid == 0 && a.m_out) *a.m_out = m;
     for (int r = m + tid; r < m_pad; r += NT) {
         a.idx[r] = -1;
         a.zrow[r] = 0.f;
@@ -886,8 +887,8 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
         {
             ProfScope ps(f, PC_GEMM_PREDICT, 4.0 * n * (double)n * n);
             // X = F*P (B = P is [K x N]); P' = X*F^T (B = F is [N x K])
-            launch_gemm(f->stream, 0, n, n, np, 1.f, f->Fdense, ld, f->P, ld, 0.f, nullptr, 0, f->P2, ld, 0);
-            launch_gemm(f->stream, 1, n, n, np, 1.f, f->P2, ld, f->Fdense, ld, 0.f, nullptr, 0, f->P, ld, 0);
+            launch_gemm(f, 0, n, n, np, 1.f, f->Fdense, ld, f->P, ld, 0.f, nullptr, 0, f->P2, ld, 0);
+            launch_gemm(f, 1, n, n, np, 1.f, f->P2, ld, f->Fdense, ld, 0.f, nullptr, 0, f->P, ld, 0);
         }
         ProfScope ps(f, PC_PREDICT);
         hipLaunchKernelGGL(add_noise_flush_kernel, grid, dim3(256), 0, f->stream, f->P, ld, n, dt);
@@ -911,7 +912,8 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
 
 // updateWithFeaturePositions (:475-628) on device-resident z/R/pass; m = 2*(#passed) known to the host
 void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, const uint8_t* d_pass, int* d_frame_counter,
-                   int frames, bool bookkeeping_done) {
+                   int frames, bool bookkeeping_done, bool m_on_device) {
+    if (m_on_device) m = 2 * f->N;  // upper bound: sizes the launches; the kernels read the true count from f->info[2]
     const int n = f->n, ld = f->ldp;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     const int n_pad = round_up(n, EKF_TILE);
@@ -927,15 +929,18 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     }
     {
         ProfScope ps(f, PC_GATHER);
-        if (!bookkeeping_done)
-            hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream,
-                               make_book_args(f, m, d_z, d_R, d_pass, d_frame_counter));
+        if (!bookkeeping_done) {
+            BookArgs bk = make_book_args(f, m, d_z, d_R, d_pass, d_frame_counter);
+            if (m_on_device) bk.m_out = f->info + 2;
+            hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, bk);
+        }
         if (m > 0) {
             if (fused_gather) {
                 // the gather and the factorisation of the first diagonal tile share one launch (chol.hip)
-                launch_gather_potrf(f, m, m_pad, n_pad);
+                launch_gather_potrf(f, m, m_pad, n_pad, m_on_device);
             } else {
-                const GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+                GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+                if (m_on_device) ga.m_dev = f->info + 2;
                 const int nb2 = (m_pad / 64) * (ld / 64);  // 64x64 transposing tiles of Wt
                 hipLaunchKernelGGL(gather_kernel, dim3(ga.nb1 + nb2), dim3(256), 0, f->stream, ga);
             }
@@ -963,8 +968,8 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             e1.Rm = f->Rm;
             e1.G = f->Gm;
             e1.ldg = ld;
-            launch_gemm(f->stream, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
-            launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
+            launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
+            launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
         }
     } else {
         // no measurement: products are empty, only the quaternion renormalisation remains (:605-609)
@@ -985,8 +990,8 @@ void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
     e1.ldg = ld;
     e2.mode = 2;  // n = 0: no mean update, no frame counter
     for (int r = 0; r < reps; r++) {
-        launch_gemm(f->stream, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P2, ld, 0, 0, &e1);
-        launch_gemm(f->stream, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P2, ld, f->P2, ld, 1, 0, &e2);
+        launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P2, ld, 0, 0, &e1);
+        launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P2, ld, f->P2, ld, 1, 0, &e2);
     }
 }
 

@@ -24,8 +24,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Diagnostic cycle stamps (s_memtime) of workgroup (0,0), wave 0; nullptr in production.
-__device__ long long* g_gemm_stamps = nullptr;
+// Diagnostic cycle stamps (s_memtime) of one workgroup's wave 0 go to GemmEpi::stamps (per handle; null in production).
 #ifdef EKF_GEMM_STAMPS  // build with -DEKF_GEMM_STAMPS for scripts/gemm_stamps.py
 #define GSTAMP(i)                                                                                  \
     do {                                                                                           \
@@ -55,7 +54,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     constexpr int LDB_S = TRANSB ? LDS_BT : LDS_BN;
 
 #ifdef EKF_GEMM_STAMPS
-    long long* stamps_ = (blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) ? g_gemm_stamps : nullptr;
+    long long* stamps_ = (blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) ? epi.stamps : nullptr;
 #endif
     GSTAMP(0);
     const int grp = (GROUPS > 1) ? (threadIdx.x >> 8) : 0;
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     const int j0 = (swz / tiles_x) * 64;
 
 #ifdef EKF_GEMM_STAMPS
-    long long* stamps_ = (blockIdx.x == 9 && threadIdx.x == 0) ? g_gemm_stamps : nullptr;
+    long long* stamps_ = (blockIdx.x == 9 && threadIdx.x == 0) ? epi.stamps : nullptr;
 #endif
     GSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -683,19 +682,15 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
 
 // cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
 // (512 threads); +100 = the same with 256 threads
-static void launch_gemm_cfg(hipStream_t s, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                             const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                             int lowerB, const GemmEpi* epi) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     GemmEpi e;
     if (epi) e = *epi;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0)
-            cus = 256;
-    }
+    hipStream_t s = f->stream;
+    e.stamps = f->gemm_stamps;
+    const int cus = f->num_cus > 0 ? f->num_cus : 256;  // per handle: handles on different devices may differ
     const int ty = (N + 63) / 64;
     if (cfg == 0) {
         cfg = 1;
@@ -750,19 +745,18 @@ static void launch_gemm_cfg(hipStream_t s, int cfg, int transB, int M, int N, in
 #undef GEMM_GO
 }
 
-void launch_gemm(hipStream_t s, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+void launch_gemm(ekfvio_filter* f, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                  int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB,
                  const GemmEpi* epi) {
-    launch_gemm_cfg(s, 0, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, epi);
+    launch_gemm_cfg(f, 0, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, epi);
 }
 
 // variant: 0 = production choice, 1 = 64x64 tiles / 256 threads, 2 = 64x64 / 512 threads, 32 / 48 / 64 = BM of gemm16_kernel
-void launch_gemm_variant(hipStream_t s, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+void launch_gemm_variant(ekfvio_filter* f, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,
                          int lowerB) {
     if (variant >= 32 && (!transB || K % 64 != 0)) variant = 1;
     if (variant >= 32 && variant % 100 != 32 && variant % 100 != 48 && variant % 100 != 64) variant = 0;
-    launch_gemm_cfg(s, variant, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, nullptr);
+    launch_gemm_cfg(f, variant, transB, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, ldc, flush, lowerB, nullptr);
 }
 
-void gemm_set_stamp_buffer(long long* d_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &d_buf, sizeof(d_buf)); }

@@ -23,6 +23,8 @@
 // 64-bit wave reductions.
 #include <math.h>
 
+#include <string.h>
+
 #include "common.h"
 
 #define KLT_BORDER 24     // >= window size (21); multiple of 8
@@ -361,6 +363,32 @@ __global__ void klt_points_kernel(const float* __restrict__ last_klt, const floa
     next_px[2 * i + 1] = fyc * mu[EKF_BASE + 3 * i + 1] + cyc;
 }
 
+// EKFVIO::publishPoints (EKFVIO.cpp:479-518): camera-frame point (u/rho, v/rho, 1/rho) per landmark -- p(2) = 1.0/p(2)
+// in double, narrowed, then two float products -- and the "intensity" channel f.img.at<uchar>(e.getPixel(f)): the byte
+// at the landmark's pixel (Feature::getPixel: K(0)*mu(0) + K(2), K(4)*mu(1) + K(5); cv::Point2f -> cv::Point rounds
+// to nearest even, cvRound).  The reference reads outside the image unchecked; here such a landmark gets intensity 0.
+// img = pixel (0,0) of level 0 of the current frame, or null when no frame has been pushed (intensity 0 then).
+__global__ void points_kernel(const float* __restrict__ mu, int N, const uint8_t* __restrict__ img, int pitch, int w, int h,
+                              float fx, float fy, float cx, float cy, float* __restrict__ xyz, float* __restrict__ intensity) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float u = mu[EKF_BASE + 3 * i], v = mu[EKF_BASE + 3 * i + 1], rho = mu[EKF_BASE + 3 * i + 2];
+    const float z = (float)(1.0 / (double)rho);
+    xyz[3 * i] = u * z;
+    xyz[3 * i + 1] = v * z;
+    xyz[3 * i + 2] = z;
+    float in = 0.f;
+    if (img) {
+        const float px = fx * u + cx, py = fy * v + cy;
+        // cvRound; compared as floats first so that NaN / huge values never reach the conversion
+        if (px >= -0.5f && px < (float)w && py >= -0.5f && py < (float)h) {
+            const int ix = __float2int_rn(px), iy = __float2int_rn(py);
+            if (ix >= 0 && ix < w && iy >= 0 && iy < h) in = (float)img[(size_t)iy * pitch + ix];
+        }
+    }
+    intensity[i] = in;
+}
+
 // ---- KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) -------------------
 // cv::getRectSubPix(8-bit, Size(5,5), center, CV_32F) (OpenCV 3.x samplers.cpp, getRectSubPix_8u32f): one patch row.
 // Inside the image the horizontal interpolation is carried from pixel to pixel through a double factor
@@ -531,6 +559,7 @@ int klt_alloc(ekfvio_filter* f) {
     HIPK(f, hipMalloc((void**)&f->klt_status, maxf));
     HIPK(f, hipMalloc((void**)&f->klt_cov_px, sizeof(float) * 4 * maxf));
     HIPK(f, hipMalloc((void**)&f->staging, (size_t)c.max_image_width * c.max_image_height));
+    HIPK(f, hipHostMalloc((void**)&f->h_image, (size_t)c.max_image_width * c.max_image_height, hipHostMallocDefault));
     return EKFVIO_OK;
 }
 
@@ -545,6 +574,7 @@ void klt_free(ekfvio_filter* f) {
     if (f->klt_status) (void)hipFree(f->klt_status);
     if (f->klt_cov_px) (void)hipFree(f->klt_cov_px);
     if (f->staging) (void)hipFree(f->staging);
+    if (f->h_image) (void)hipHostFree(f->h_image);
 }
 
 // Device-side part of klt_push_frame: staging -> pyramid + derivatives of frames[cur]
@@ -640,10 +670,12 @@ int klt_track_device(ekfvio_filter* f) {
     return EKFVIO_OK;
 }
 
-extern "C" {
-
-int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
-                          const float K[9]) {
+// Frame ingest without a host wait: the caller's image is copied into the handle's pinned staging buffer (so the
+// caller may reuse its buffer on return), then H2D, resize and pyramid are enqueued on the handle's stream.  The pinned
+// buffer is rewritten by the next frame, so the previous frame's H2D copy must have completed by then: the callers
+// below synchronise the stream before they return.
+static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                              const float K[9]) {
     if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
     if (width > f->cfg.max_image_width || height > f->cfg.max_image_height) return EKFVIO_ECAPACITY;
     // Frame::Frame (Frame.cpp:15-42): cv::resize to (cols / s, rows / s), K(0,0), K(0,2), K(1,1), K(1,2) divided by s
@@ -651,7 +683,12 @@ int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width,
     const int w = width / s, h = height / s;
     if (w < 1 || h < 1) return EKFVIO_EINVAL;
     HIPK(f, hipSetDevice(f->device));
-    HIPK(f, hipMemcpy2DAsync(f->staging, width, image, stride, width, height, hipMemcpyHostToDevice, f->stream));
+    if (stride == width) {
+        memcpy(f->h_image, image, (size_t)width * height);
+    } else {
+        for (int y = 0; y < height; y++) memcpy(f->h_image + (size_t)y * width, image + (size_t)y * stride, width);
+    }
+    HIPK(f, hipMemcpyAsync(f->staging, f->h_image, (size_t)width * height, hipMemcpyHostToDevice, f->stream));
     f->cur ^= 1;  // the former current frame becomes the previous one (frame_buffer depth 2)
     KltFrame& fr = f->frames[f->cur];
     for (int i = 0; i < 9; i++) fr.K[i] = K[i];
@@ -665,7 +702,47 @@ int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width,
     build_pyramid(f, fr, s > 1 ? f->resized : f->staging, w, h);
     fr.valid = true;
     HIPK(f, hipGetLastError());
-    HIPK(f, hipStreamSynchronize(f->stream));  // the caller's image buffer may be reused
+    return EKFVIO_OK;
+}
+
+extern "C" {
+
+int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                          const float K[9]) {
+    const int rc = push_frame_enqueue(f, image, width, height, stride, K);
+    if (rc != EKFVIO_OK) return rc;
+    HIPK(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+// publishPoints' payload (EKFVIO.cpp:479-518), formed on the device: xyz3N = (u/rho, v/rho, 1/rho) per landmark in the
+// camera frame, intensityN = the current (resized) frame's byte at the landmark's pixel (0 outside the image or before
+// the first frame).  Either pointer may be NULL.
+int ekfvio_get_points(ekfvio_filter* f, float* xyz3N, float* intensityN) {
+    if (!f) return EKFVIO_EINVAL;
+    const int N = f->N;
+    if (N == 0) return EKFVIO_OK;
+    HIPK(f, hipSetDevice(f->device));
+    const KltFrame& fr = f->frames[f->cur];
+    const uint8_t* img = nullptr;
+    int pitch = 0, w = 0, h = 0;
+    float fx = 0.f, fy = 0.f, cx = 0.f, cy = 0.f;
+    if (fr.valid) {
+        pitch = level_pitch(fr.w[0]);
+        img = fr.img[0] + (size_t)KLT_BORDER * pitch + KLT_BORDER;
+        w = fr.w[0];
+        h = fr.h[0];
+        intrinsics(f, fr.K, &fx, &fy, &cx, &cy);
+    }
+    // Rmeas (4 floats per landmark) is free between updates: xyz in its first 3N floats, the intensities behind them
+    float* d_xyz = f->Rmeas;
+    float* d_int = f->Rmeas + 3 * (size_t)N;
+    hipLaunchKernelGGL(points_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->mu, N, img, pitch, w, h, fx, fy, cx, cy,
+                       d_xyz, d_int);
+    if (xyz3N) HIPK(f, hipMemcpyAsync(xyz3N, d_xyz, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, f->stream));
+    if (intensityN) HIPK(f, hipMemcpyAsync(intensityN, d_int, sizeof(float) * N, hipMemcpyDeviceToHost, f->stream));
+    HIPK(f, hipGetLastError());
+    HIPK(f, hipStreamSynchronize(f->stream));
     return EKFVIO_OK;
 }
 
@@ -750,7 +827,9 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
     if (!f) return EKFVIO_EINVAL;
     const bool first = !f->frames[f->cur].valid;
     if (!first && f->have_stamp && !(stamp - f->t_stamp >= 0)) return EKFVIO_EINVAL;  // ROS_ASSERT(dt >= 0)
-    int rc = ekfvio_klt_push_frame(f, image, width, height, stride, K);
+    // nothing below waits for the device until the status word is read at the very end: the frame upload, the
+    // pyramid, process(dt), the tracker and the update are enqueued back to back
+    int rc = push_frame_enqueue(f, image, width, height, stride, K);
     if (rc != EKFVIO_OK) return rc;
     if (first) {
         // first frame: remember the stamp (tc_ekf.t = f.t) and return; the caller replenishes
@@ -759,6 +838,7 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
             f->have_stamp = true;
         }
         if (f->cfg.replenish) return ekfvio_replenish(f, nullptr, nullptr);  // replenishFeatures(first frame) (:154)
+        HIPK(f, hipStreamSynchronize(f->stream));
         return EKFVIO_OK;
     }
     const float dt = (float)(stamp - f->t_stamp);
@@ -769,23 +849,21 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
     if (f->N > 0) {  // "run update if we have enough features" (EKFVIO.cpp:166)
         rc = klt_track_device(f);
         if (rc != EKFVIO_OK) return rc;
-        std::vector<uint8_t> hp(f->N);
-        HIPK(f, hipMemcpyAsync(hp.data(), f->pass, f->N, hipMemcpyDeviceToHost, f->stream));
-        HIPK(f, hipStreamSynchronize(f->stream));
-        int m = 0;
-        for (int i = 0; i < f->N; i++) m += hp[i] ? 2 : 0;
-        launch_update(f, m, f->zmeas, f->Rmeas, f->pass);
-        HIPK(f, hipMemcpyAsync(f->h_info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
-        HIPK(f, hipStreamSynchronize(f->stream));
-        if (f->h_info[0]) {
-            status = EKFVIO_ENUMERIC;
-            HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
-        }
+        // the pass flags stay on the device: the update is launched for m = 2N measurement rows and its kernels take
+        // the true count from the bookkeeping (rows beyond it are identity padding, exact zeros in every product)
+        launch_update(f, 0, f->zmeas, f->Rmeas, f->pass, nullptr, 0, false, true);
     }
     HIPK(f, hipGetLastError());
     if (f->cfg.replenish) {  // "try to get more features if needed" (:172)
         rc = ekfvio_replenish(f, nullptr, nullptr);
         if (rc != EKFVIO_OK) return rc;
+    }
+    // the frame's single host wait: status word of the factorisation
+    HIPK(f, hipMemcpyAsync(f->h_info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    HIPK(f, hipStreamSynchronize(f->stream));
+    if (f->h_info[0]) {
+        status = EKFVIO_ENUMERIC;
+        HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
     }
     return status;
 }

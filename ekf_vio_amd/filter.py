@@ -40,8 +40,9 @@ class TightlyCoupledEKF:
         self.h = C.c_void_p()
         rc = self.lib.ekfvio_create(C.byref(cfg), device, C.c_void_p(stream) if stream else None, C.byref(self.h))
         if rc != capi.OK:
-            msg = self.lib.ekfvio_last_error(self.h).decode() if self.h else ""
-            raise capi.EkfvioError(rc, msg)
+            # a failed create releases whatever it had allocated and hands back no handle
+            self.h = None
+            raise capi.EkfvioError(rc, "ekfvio_create failed (device %d)" % device)
 
     def _chk(self, rc, allow=()):
         if rc != capi.OK and rc not in allow:
@@ -102,6 +103,25 @@ class TightlyCoupledEKF:
         cov = np.zeros(4, np.float32)
         self._chk(self.lib.ekfvio_get_feature_cov(self.h, index, _fp(cov)))
         return cov.reshape(2, 2).T.copy()
+
+    def setFeatureHomogenousCovariance(self, index, cov):
+        """TightlyCoupledEKF.cpp:668-676; cov is [row, col]."""
+        c = np.ascontiguousarray(np.asarray(cov, np.float32).reshape(2, 2).T)  # column-major buffer
+        self._chk(self.lib.ekfvio_set_feature_cov(self.h, int(index), _fp(c)))
+
+    def getMetric2PixelMap(self, K):
+        """TightlyCoupledEKF.cpp:683-689: diag(K(0,0), K(1,1)) as a dense 2x2."""
+        K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        J = np.zeros(4, np.float32)
+        self._chk(self.lib.ekfvio_metric2pixel_map(_fp(K), _fp(J)))
+        return J.reshape(2, 2).T.copy()
+
+    def getPixel2MetricMap(self, K):
+        """TightlyCoupledEKF.cpp:691-697: diag(1/K(0,0), 1/K(1,1))."""
+        K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        J = np.zeros(4, np.float32)
+        self._chk(self.lib.ekfvio_pixel2metric_map(_fp(K), _fp(J)))
+        return J.reshape(2, 2).T.copy()
 
     def getFeatureDepthVariance(self, index):
         v = C.c_float(0)
@@ -165,7 +185,8 @@ class TightlyCoupledEKF:
         self._chk(self.lib.ekfvio_run_uploaded(self.h, first, count, float(dt)))
 
     def synchronize(self):
-        self._chk(self.lib.ekfvio_synchronize(self.h))
+        """Waits for the handle's stream; returns capi.ENUMERIC once if an asynchronous run met a non-positive pivot."""
+        return self._chk(self.lib.ekfvio_synchronize(self.h), allow=(capi.ENUMERIC,))
 
     # ---- instrumentation ---------------------------------------------------------------
     def profile(self, on):
@@ -275,7 +296,8 @@ def _ip(a):
 class EKFVIO:
     """Host mirror of the step sequence of EKFVIO::addFrame / updateStateWithNewImage
     (include/ekf_vio/EKFVIO.cpp:139-219) without ROS: frames in, odometry + landmark cloud out.
-    Landmark replenishment (FAST, EKFVIO.cpp:224-311) stays with the caller."""
+    With replenish=1 in the configuration addFrame also runs replenishFeatures (FAST, EKFVIO.cpp:224-311)
+    on the device; otherwise call replenishFeatures() (or addNewFeatures) yourself."""
 
     def __init__(self, **kw):
         self.tc_ekf = TightlyCoupledEKF(**kw)
@@ -315,10 +337,14 @@ class EKFVIO:
 
     def odometry(self):
         """What publishOdometry sends (EKFVIO.cpp:444-477): position, orientation (w,x,y,z), twist."""
-        b = self.tc_ekf.base_mu
-        return dict(position=b[0:3], orientation_wxyz=b[3:7], linear=b[7:10], angular=b[10:13])
+        p, q, l, a = (np.zeros(k, np.float32) for k in (3, 4, 3, 3))
+        self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_get_odometry(self.tc_ekf.h, _fp(p), _fp(q), _fp(l), _fp(a)))
+        return dict(position=p, orientation_wxyz=q, linear=l, angular=a)
 
     def points(self):
-        """publishPoints (EKFVIO.cpp:479-518): camera-frame xyz = (u/rho, v/rho, 1/rho) per landmark."""
-        f = self.tc_ekf.get_state()["feat_mu"]
-        return np.stack([f[:, 0] / f[:, 2], f[:, 1] / f[:, 2], 1.0 / f[:, 2]], axis=1)
+        """publishPoints (EKFVIO.cpp:479-518), formed on the device: (xyz[N,3], intensity[N]) = camera-frame
+        (u/rho, v/rho, 1/rho) per landmark and the current frame's byte at the landmark's pixel."""
+        N = self.tc_ekf.num_features
+        xyz, inten = np.zeros((N, 3), np.float32), np.zeros(N, np.float32)
+        self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_get_points(self.tc_ekf.h, _fp(xyz), _fp(inten)))
+        return xyz, inten

@@ -199,6 +199,19 @@ class TightlyCoupledEKF {
         chk(ekfvio_get_feature_cov(h_, index, m.data()));
         return m;
     }
+    // TightlyCoupledEKF.cpp:668-676
+    void setFeatureHomogenousCovariance(int index, const Matrix2f& cov) { chk(ekfvio_set_feature_cov(h_, index, cov.data())); }
+    // TightlyCoupledEKF.cpp:683-697 (K row-major 3x3 as in CameraInfo.K; the reference returns a 2x2 sparse matrix)
+    static Matrix2f getMetric2PixelMap(const std::array<float, 9>& K) {
+        Matrix2f J;
+        ekfvio_metric2pixel_map(K.data(), J.data());
+        return J;
+    }
+    static Matrix2f getPixel2MetricMap(const std::array<float, 9>& K) {
+        Matrix2f J;
+        ekfvio_pixel2metric_map(K.data(), J.data());
+        return J;
+    }
     float getFeatureDepthVariance(int index) {
         float v = 0;
         chk(ekfvio_get_depth_variance(h_, index, &v));
@@ -267,6 +280,20 @@ class KLTTracker {
     TightlyCoupledEKF& ekf_;
 };
 
+// publishOdometry's payload (EKFVIO.cpp:444-477) and publishPoints' (EKFVIO.cpp:479-518) as plain records: what the
+// node copies into nav_msgs/Odometry (+ the world -> odom tf) and sensor_msgs/PointCloud with its "intensity" channel.
+struct Odometry {
+    double stamp = 0;
+    Vector3f position{};
+    std::array<float, 4> orientation_wxyz{};
+    Vector3f linear{}, angular{};
+};
+struct PointCloud {
+    double stamp = 0;
+    std::vector<Vector3f> points;   // camera frame: (u/rho, v/rho, 1/rho)
+    std::vector<float> intensity;   // image byte at the landmark's pixel
+};
+
 // The step sequence of EKFVIO::addFrame (EKFVIO.cpp:139-196) with the ROS plumbing removed.
 class EKFVIO {
    public:
@@ -292,13 +319,33 @@ class EKFVIO {
     // returns false on a numeric warning (see updateWithFeaturePositions)
     bool addFrame(const Frame& f) {
         int rc = ekfvio_step_image(tc_ekf.handle(), f.t, f.img, f.cols, f.rows, f.step, f.K.data());
+        last_stamp_ = f.t;
         if (rc == EKFVIO_ENUMERIC) return false;
         tc_ekf.chk(rc);
         return true;
     }
+    // what publishOdometry(cf) / publishPoints(cf) send after addFrame (EKFVIO.cpp:182-188)
+    Odometry odometry() {
+        Odometry o;
+        o.stamp = last_stamp_;
+        tc_ekf.chk(ekfvio_get_odometry(tc_ekf.handle(), o.position.data(), o.orientation_wxyz.data(), o.linear.data(), o.angular.data()));
+        return o;
+    }
+    PointCloud points() {
+        PointCloud c;
+        c.stamp = last_stamp_;
+        const int N = tc_ekf.numFeatures();
+        c.points.resize(N);
+        c.intensity.resize(N);
+        tc_ekf.chk(ekfvio_get_points(tc_ekf.handle(), N ? c.points[0].data() : nullptr, N ? c.intensity.data() : nullptr));
+        return c;
+    }
     void imu_callback(double stamp, const Vector3f& gyro, const Vector3f& accel) {
         tc_ekf.chk(ekfvio_imu(tc_ekf.handle(), stamp, gyro.data(), accel.data()));
     }
+
+   private:
+    double last_stamp_ = 0;
 };
 
 }  // namespace ekfvio

@@ -77,7 +77,8 @@ int ekfvio_default_config(ekfvio_config* cfg);
 
 /* TightlyCoupledEKF::TightlyCoupledEKF() + initializeBaseState()
  * (TightlyCoupledEKF.cpp:10-56).  `device` is a HIP device ordinal.  `stream` is an
- * existing hipStream_t to enqueue on, or NULL to let the handle create its own. */
+ * existing hipStream_t to enqueue on, or NULL to let the handle create its own.
+ * On failure nothing is left allocated and *out is NULL. */
 int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out);
 int ekfvio_destroy(ekfvio_filter* f);
 /* initializeBaseState(): back to mu = [0,0,0,1,0...], Sigma diag [0x7,30x9,0.5x6], no landmarks. */
@@ -114,6 +115,21 @@ int ekfvio_get_sigma(ekfvio_filter* f, float* sigma, int32_t ld);
 /* getFeatureHomogenousCovariance / getFeatureDepthVariance (TightlyCoupledEKF.cpp:663-681). */
 int ekfvio_get_feature_cov(ekfvio_filter* f, int32_t index, float cov2x2[4]);
 int ekfvio_get_depth_variance(ekfvio_filter* f, int32_t index, float* var);
+/* setFeatureHomogenousCovariance(index, cov) (TightlyCoupledEKF.cpp:668-676): overwrites the 2x2 (u,v) block of Sigma
+ * (column-major, like Eigen::Matrix2f). */
+int ekfvio_set_feature_cov(ekfvio_filter* f, int32_t index, const float cov2x2[4]);
+/* getMetric2PixelMap(K) / getPixel2MetricMap(K) (TightlyCoupledEKF.cpp:683-697): J = diag(K(0,0), K(1,1)) and
+ * diag(1/K(0,0), 1/K(1,1)), column-major 2x2; K row-major 3x3 as in CameraInfo.K.  Pure functions of K. */
+int ekfvio_metric2pixel_map(const float K[9], float J2x2[4]);
+int ekfvio_pixel2metric_map(const float K[9], float J2x2[4]);
+/* What EKFVIO::publishOdometry puts into nav_msgs/Odometry (EKFVIO.cpp:444-477): position base_mu[0..2], orientation
+ * (w,x,y,z) base_mu[3..6], linear twist base_mu[7..9], angular twist base_mu[10..12].  Any pointer may be NULL. */
+int ekfvio_get_odometry(ekfvio_filter* f, float position[3], float orientation_wxyz[4], float linear[3], float angular[3]);
+/* What EKFVIO::publishPoints puts into sensor_msgs/PointCloud (EKFVIO.cpp:479-518), formed on the device: camera-frame
+ * xyz = (u/rho, v/rho, 1/rho) per landmark and the "intensity" channel = byte of the current (resized) frame at the
+ * landmark's pixel (Feature::getPixel, rounded like cv::Point(cv::Point2f)); 0 for a pixel outside the image (the
+ * reference reads unchecked there) or before the first frame.  Either pointer may be NULL. */
+int ekfvio_get_points(ekfvio_filter* f, float* xyz3N, float* intensityN);
 /* checkSigma (TightlyCoupledEKF.cpp:699-714) as numbers: min diagonal, max |S_ij - S_ji|. */
 int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym);
 
@@ -148,8 +164,12 @@ int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h
 
 /* EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) without the ROS
  * publishing: first frame only stores the image and stamp; later frames run
- * process(dt = stamp - t), then KLT + update if landmarks exist.  Landmark replenishment
- * (FAST) stays with the caller: add landmarks with ekfvio_add_features afterwards. */
+ * process(dt = stamp - t), then KLT + update if landmarks exist.  With cfg.replenish = 1 the
+ * two replenishFeatures calls of addFrame (:154, :172) run on the device as well; with 0 the
+ * caller adds landmarks (ekfvio_replenish, or its own detector + ekfvio_add_features).
+ * The image is copied before the call returns; the call waits for the device once, at its end
+ * (status word), the pass flags of the tracker never travel to the host.
+ * Returns EKFVIO_OK or EKFVIO_ENUMERIC. */
 int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height,
                       int32_t stride, const float K[9]);
 
@@ -177,6 +197,8 @@ int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z,
  * ekfvio_synchronize.  count = 0 runs nothing but prepares the launch graphs the runs replay (their
  * capture costs milliseconds: a caller that times a run prepares first). */
 int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt);
+/* Waits for the handle's stream.  Returns EKFVIO_ENUMERIC (once) if a run since the last status read met a
+ * non-positive pivot (reference: ROS_ERROR_COND at TightlyCoupledEKF.cpp:579, continues), else EKFVIO_OK. */
 int ekfvio_synchronize(ekfvio_filter* f);
 
 /* ---- instrumentation ----------------------------------------------------------------- */

@@ -145,7 +145,8 @@ def test_config1_klt_plus_64_landmark_update():
     assert rel(sg["Sigma"], s64["Sigma"]) <= yard["sig"] + 4 * rel(so["Sigma"], s64["Sigma"]) + 2e-6, yard
     od = v.odometry()
     assert od["position"].shape == (3,) and abs(np.linalg.norm(od["orientation_wxyz"]) - 1) < 1e-6
-    assert v.points().shape == (64, 3)
+    xyz, inten = v.points()
+    assert xyz.shape == (64, 3) and inten.shape == (64,)
     v.tc_ekf.close()
 
 
@@ -209,3 +210,65 @@ def test_sample_based_uncertainty_feeds_the_update_behind_its_flag():
     assert np.allclose(out[1][1][ok], want[ok], rtol=1e-3, atol=1e-9)
     assert np.allclose(out[0][1][ok][:, 0], np.float32(1e-5) * s0) and (out[0][1][ok][:, 1] == 0).all()
     assert (out[1][1][~ok] == 0).all()
+
+
+def test_points_payload_matches_the_reference_arithmetic():
+    """A19: publishPoints (EKFVIO.cpp:479-518) formed on the device: xyz = (u * z, v * z, z) with z = 1.0 / rho evaluated
+    in double and narrowed, intensity = image byte at cv::Point(getPixel(f)) (round half to even; K(2) = K(5) = 0 by
+    the Feature.h indexing quirk), and publishOdometry's slices of base_mu."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    px = np.vstack([grid_points(8)[:60], [[0.5, 0.5], [638.5, 478.49], [700.0, 100.0], [-3.0, 50.0]]]).astype(np.float32)
+    v = EKFVIO(max_features=64)
+    assert v.points()[0].shape == (0, 3)
+    v.addFrame(1.0, a, K)
+    v.tc_ekf.addNewFeatures(_metric(px))
+    xyz0, int0 = v.points()  # before any update: the landmarks sit exactly on their pixels of frame a
+    v.addFrame(1.0 + 1.0 / 30.0, b, K)
+    for img, (xyz, inten) in ((a, (xyz0, int0)), (b, v.points())):
+        f = v.tc_ekf.get_state()["feat_mu"] if img is b else np.concatenate([_metric(px), np.full((64, 1), 2.0, np.float32)], axis=1)
+        z = (1.0 / f[:, 2].astype(np.float64)).astype(np.float32)
+        want = np.stack([f[:, 0] * z, f[:, 1] * z, z], axis=1)
+        assert np.array_equal(xyz, want)
+        pxf = np.float32(K[0]) * f[:, 0], np.float32(K[4]) * f[:, 1]
+        ix, iy = np.rint(pxf[0]).astype(np.int64), np.rint(pxf[1]).astype(np.int64)
+        inside = (ix >= 0) & (ix < 640) & (iy >= 0) & (iy < 480)
+        wi = np.where(inside, img[np.clip(iy, 0, 479), np.clip(ix, 0, 639)], 0).astype(np.float32)
+        assert np.array_equal(inten, wi)
+        assert inside.sum() >= 60 and (~inside).sum() >= 2
+    od, bm = v.odometry(), v.tc_ekf.base_mu
+    assert np.array_equal(od["position"], bm[0:3]) and np.array_equal(od["orientation_wxyz"], bm[3:7])
+    assert np.array_equal(od["linear"], bm[7:10]) and np.array_equal(od["angular"], bm[10:13])
+    v.tc_ekf.close()
+
+
+def test_step_image_with_device_side_row_count_equals_the_host_sized_update():
+    """ekfvio_step_image leaves the tracker's pass flags on the device and launches the update for m = 2N rows (the true
+    count is read by the kernels; the rest is identity padding).  Against the explicit sequence push_frame / process /
+    findNewFeaturePositions / updateWithFeaturePositions, which sizes the launches from the host-known m, every bit of
+    the state must agree -- here with 24 of 64 landmarks tracked, so the two paths really use different paddings
+    (m_pad 64 vs 128)."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    good = grid_points(8)[[9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 25, 26, 27, 28, 29, 30, 33, 34, 35, 36, 37, 38]]
+    bad = np.array([[-50.0 - 3 * i, 40.0 + 5 * i] for i in range(20)] + [[660.0 + 2 * i, 100.0 + 7 * i] for i in range(20)], np.float32)
+    px = np.vstack([good[:12], bad[:20], good[12:], bad[20:]]).astype(np.float32)
+    uv = _metric(px)
+    t0, t1 = 3.0, 3.0 + 1.0 / 30.0
+    v = EKFVIO(max_features=64)
+    v.addFrame(t0, a, K)
+    v.tc_ekf.addNewFeatures(uv)
+    rc_a = v.addFrame(t1, b, K)
+    w = TightlyCoupledEKF(max_features=64)
+    tr = KLTTracker(w)
+    tr.push_frame(a, K)
+    w.addNewFeatures(uv)
+    tr.push_frame(b, K)
+    w.process(np.float32(np.float64(t1) - np.float64(t0)))
+    z, R, p = tr.findNewFeaturePositions()
+    assert 16 <= int(p.sum()) <= 24  # m_pad = 64 on this path
+    rc_b = w.updateWithFeaturePositions(z, R, p)
+    assert rc_a == rc_b
+    sa, sb = v.tc_ekf.get_state(), w.get_state()
+    for k in ("base_mu", "feat_mu", "last_klt", "del_flag", "Sigma"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert sa["del_flag"].sum() == 64 - int(p.sum())
+    v.tc_ekf.close(), w.close()

@@ -1,0 +1,228 @@
+"""Oracle parity at the shapes the product ships and the bench times.
+
+tests/test_gpu_parity.py compares the update with the oracle at N <= 100, where the GEMM launcher picks 32-row
+tiles.  Here the same teacher-forced policy runs at
+  * N = 256 (n = 790, m <= 512): gemm16_kernel<48,2,1|2> with the Joseph epilogues (G, the K*y column, the mean and
+    quaternion finish), the fused gather + first diagonal tile, 7 block steps -- including frames where 10 and 40
+    landmarks failed (m = 492 / 432: ragged last tile, another m_pad);
+  * N = 1024 (n = 3094, m = 2048): gemm_f32_mfma_kernel<true,1,1|2>, the split sweep (panel launch + update launch),
+    the un-fused gather and linearisation;
+plus checkSigma's two numbers against the oracle's and the config-4 stand-in: eight live handles on one GPU, calls
+interleaved, each bit-identical to its solo run.
+
+Tolerances are those of tests/test_gpu_parity.py (written there): bookkeeping and process(dt) bit-exact; update: the
+HIP forward error against the fp64 evaluation of the same step at most ACC_FACTOR x the fp32 oracle's + a floor.
+"""
+import numpy as np
+import pytest
+
+from ekf_vio_amd import TightlyCoupledEKF, capi
+from ekf_vio_amd.sim import Scenario
+from oracle import OracleFilter, max_threads, set_threads
+
+pytestmark = pytest.mark.gpu
+
+ACC_FACTOR = 4.0
+MU_FLOOR = 2e-5
+SIG_FLOOR = 2e-6
+
+
+def relf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if np.size(a) else 0.0
+
+
+def to32(st):
+    return {k: (v.astype(np.float32) if v.dtype == np.float64 else v.copy()) for k, v in st.items()}
+
+
+@pytest.fixture()
+def oracle_threads():
+    """The oracle's OpenMP products on every core the box gives us (results do not depend on the thread count:
+    each output element is summed by one thread in a fixed order)."""
+    set_threads(min(max_threads(), 16))
+    yield
+    set_threads(1)
+
+
+def _teacher_forced(g, o32, o64, st32, dt, z, R, p):
+    """One teacher-forced process + update from the fp32 state st32.  Returns the error dictionary of the update."""
+    g.set_state(st32), o32.set_state(st32)
+    g.process(dt), o32.process(dt)
+    sg, so = g.get_state(), o32.get_state()
+    for k in ("base_mu", "feat_mu", "Sigma"):
+        assert np.array_equal(sg[k], so[k]), ("process", k)
+    st = o32.get_state()
+    g.set_state(st), o64.set_state(st)
+    assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+    assert o32.update(z, R, p) == 0
+    o64.update(z, R, p)
+    sg, s32, s64 = g.get_state(), o32.get_state(), o64.get_state()
+    assert np.array_equal(sg["del_flag"], s32["del_flag"]) and np.array_equal(sg["last_klt"], s32["last_klt"])
+    assert abs(np.linalg.norm(sg["base_mu"][3:7]) - 1) < 1e-6
+    return dict(mu_gpu=maxabs(sg["base_mu"], s64["base_mu"]), mu_o32=maxabs(s32["base_mu"], s64["base_mu"]),
+                feat_gpu=maxabs(sg["feat_mu"], s64["feat_mu"]), feat_o32=maxabs(s32["feat_mu"], s64["feat_mu"]),
+                sig_gpu=relf(sg["Sigma"], s64["Sigma"]), sig_o32=relf(s32["Sigma"], s64["Sigma"]),
+                sig_pair=relf(sg["Sigma"], s32["Sigma"])), s64
+
+
+def _assert_within_yardstick(E):
+    assert E["mu_gpu"] <= ACC_FACTOR * E["mu_o32"] + MU_FLOOR, E
+    assert E["feat_gpu"] <= ACC_FACTOR * E["feat_o32"] + MU_FLOOR, E
+    assert E["sig_gpu"] <= ACC_FACTOR * E["sig_o32"] + SIG_FLOOR, E
+
+
+def test_teacher_forced_n256_including_failed_landmarks(oracle_threads):
+    """BASELINE config 2's shape.  The teacher trajectory is the fp64 oracle's (so every step starts from a sane,
+    converged state: the raw prior's cond(S) ~ 1e7 first update is covered at N <= 100 with its own yardstick)."""
+    N = 256
+    sc = Scenario(N, seed=0)
+    g = TightlyCoupledEKF(max_features=N)
+    o32, o64, teacher = OracleFilter(np.float32), OracleFilter(np.float64), OracleFilter(np.float64)
+    uv = sc.initial_features()
+    g.addNewFeatures(uv), teacher.add_new_features(uv)
+    frames = list(sc.frames(9))
+    for z, R, p in frames[:5]:
+        teacher.process(sc.dt), teacher.update(z, R, p)
+    worst = None
+    fails = {1: 10, 3: 40}  # step -> number of landmarks the tracker lost in that frame
+    for s, (z, R, p) in enumerate(frames[5:]):
+        p = p.copy()
+        for q in range(fails.get(s, 0)):
+            p[(17 * q + 5 * s + 3) % N] = 0
+        m = 2 * int(p.sum())
+        assert m == 2 * (N - fails.get(s, 0))
+        E, _ = _teacher_forced(g, o32, o64, to32(teacher.get_state()), sc.dt, z, R, p)
+        _assert_within_yardstick(E)
+        worst = E if worst is None else {k: max(worst[k], E[k]) for k in E}
+        teacher.process(sc.dt), teacher.update(z, R, p)
+    # the two fp32 evaluations differ in rounding order only
+    assert worst["sig_pair"] < 1e-4, worst
+    g.close()
+
+
+def test_teacher_forced_one_step_n1024(oracle_threads):
+    """BASELINE config 3's shape: one teacher-forced step.  The starting state comes from the HIP filter's own first
+    steps (cheap); the compared step itself is evaluated by all three from identical fp32 inputs."""
+    N = 1024
+    sc = Scenario(N, seed=0)
+    g = TightlyCoupledEKF(max_features=N)
+    g.addNewFeatures(sc.initial_features())
+    frames = list(sc.frames(7))
+    z, R, p = (np.stack([f[i] for f in frames[:6]]) for i in range(3))
+    g.upload_measurements(z, R, p)
+    g.run_uploaded(0, 6, sc.dt)
+    assert g.synchronize() in (capi.OK, capi.ENUMERIC)  # the raw prior's first update may trip the pivot check
+    st32 = g.get_state()
+    assert np.isfinite(st32["Sigma"]).all()
+    o32, o64 = OracleFilter(np.float32), OracleFilter(np.float64)
+    zz, RR, pp = frames[6]
+    pp = pp.copy()
+    pp[[5, 77, 500, 1023]] = 0  # m = 2040, m_pad = 2048
+    E, _ = _teacher_forced(g, o32, o64, st32, sc.dt, zz, RR, pp)
+    _assert_within_yardstick(E)
+    assert E["sig_pair"] < 1e-4, E
+    g.close()
+
+
+@pytest.mark.parametrize("N", [30, 256])
+def test_check_sigma_numbers_equal_the_oracle(N):
+    """A13: checkSigma (TightlyCoupledEKF.cpp:699-714) as numbers -- smallest diagonal entry and largest
+    |Sigma_ij - Sigma_ji| -- are the same floats as the oracle's on the same covariance (min / max / abs of a
+    difference are exact operations)."""
+    sc = Scenario(N, seed=3)
+    g, o = TightlyCoupledEKF(max_features=N), OracleFilter(np.float32)
+    g.addNewFeatures(sc.initial_features())
+    for z, R, p in sc.frames(4):
+        g.process(sc.dt)
+        g.updateWithFeaturePositions(z, R, p)
+    st = g.get_state()
+    assert np.abs(st["Sigma"] - st["Sigma"].T).max() > 0  # the Joseph products do leave an asymmetry to measure
+    o.set_state(st)
+    assert g.checkSigma() == o.check_sigma()
+    # and a matrix with a negative variance and one grossly asymmetric pair
+    st["Sigma"][25, 25] = -0.5
+    st["Sigma"][3, 40] += 7.0
+    g.set_state(st), o.set_state(st)
+    md, ma = g.checkSigma()
+    assert (md, ma) == o.check_sigma() and md == -0.5 and ma >= 6.9
+    g.close()
+
+
+def test_eight_live_handles_do_not_perturb_each_other():
+    """Config 4 stand-in on one GPU: eight handles (seeds 0..7) alive at once, their calls interleaved -- per-call
+    process/update round-robin, then asynchronous device-resident runs in flight on all eight streams together --
+    must each end bit-identical to the same sequence run alone."""
+    N, steps = 256, 6
+    seqs = []
+    for seed in range(8):
+        sc = Scenario(N, seed=seed)
+        fr = list(sc.frames(2 * steps))
+        seqs.append((sc, fr))
+
+    def run_solo(sc, fr):
+        g = TightlyCoupledEKF(max_features=N)
+        g.addNewFeatures(sc.initial_features())
+        for z, R, p in fr[:steps]:
+            g.process(sc.dt)
+            g.updateWithFeaturePositions(z, R, p)
+        zz, RR, pp = (np.stack([f[i] for f in fr[steps:]]) for i in range(3))
+        g.upload_measurements(zz, RR, pp)
+        g.run_uploaded(0, steps, sc.dt)
+        g.synchronize()
+        st = g.get_state()
+        g.close()
+        return st
+
+    solo = [run_solo(sc, fr) for sc, fr in seqs]
+    hs = []
+    for sc, fr in seqs:
+        g = TightlyCoupledEKF(max_features=N)
+        g.addNewFeatures(sc.initial_features())
+        hs.append(g)
+    for s in range(steps):
+        for g, (sc, fr) in zip(hs, seqs):
+            g.process(sc.dt)
+        for g, (sc, fr) in zip(reversed(hs), reversed(seqs)):
+            g.updateWithFeaturePositions(*fr[s])
+    for g, (sc, fr) in zip(hs, seqs):
+        zz, RR, pp = (np.stack([f[i] for f in fr[steps:]]) for i in range(3))
+        g.upload_measurements(zz, RR, pp)
+        g.run_uploaded(0, 0, sc.dt)  # graphs captured before anything is in flight
+    for g, (sc, fr) in zip(hs, seqs):
+        g.run_uploaded(0, steps, sc.dt)  # asynchronous: eight streams busy together
+    for g in hs:
+        g.synchronize()
+    for i, g in enumerate(hs):
+        st = g.get_state()
+        for k in ("base_mu", "feat_mu", "last_klt", "del_flag", "Sigma"):
+            assert np.array_equal(st[k], solo[i][k]), (i, k)
+        g.close()
+    # different seeds really are different sequences
+    assert not np.array_equal(solo[0]["Sigma"], solo[1]["Sigma"])
+
+
+# ---------------------------------------------------------------- boundary additions (A12, A19)
+def test_set_feature_covariance_and_pixel_maps():
+    """setFeatureHomogenousCovariance / getMetric2PixelMap / getPixel2MetricMap (TightlyCoupledEKF.cpp:668-697)."""
+    g = TightlyCoupledEKF(max_features=8)
+    g.addNewFeatures([[0.1, 0.1], [-0.1, -0.1], [0.1, -0.1]])
+    before = g.Sigma
+    cov = np.array([[2.5e-4, -1e-5], [3e-5, 4e-4]], np.float32)  # deliberately not symmetric: four plain writes
+    g.setFeatureHomogenousCovariance(1, cov)
+    after = g.Sigma
+    s = 22 + 3
+    assert np.array_equal(after[s:s + 2, s:s + 2], cov) and np.array_equal(g.getFeatureHomogenousCovariance(1), cov)
+    after[s:s + 2, s:s + 2] = before[s:s + 2, s:s + 2]
+    assert np.array_equal(after, before)  # nothing else moved
+    with pytest.raises(capi.EkfvioError):
+        g.setFeatureHomogenousCovariance(3, cov)
+    K = np.array([512.0, 0, 321.5, 0, 498.0, 243.25, 0, 0, 1.0], np.float32)
+    assert np.array_equal(g.getMetric2PixelMap(K), np.diag([512.0, 498.0]).astype(np.float32))
+    assert np.array_equal(g.getPixel2MetricMap(K), np.diag([np.float32(1.0) / np.float32(512.0),
+                                                            np.float32(1.0) / np.float32(498.0)]).astype(np.float32))
+    g.close()
