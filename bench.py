@@ -7,13 +7,19 @@ N = 256 landmarks (n = 790 states, m = 512 measurement rows), dt = 1/30, synthet
 closed-loop sequence, measurements resident in HBM before the timed region.
 For --gpus N > 1 every rank runs an independent sequence on its own GPU (the filter is
 sequential per step; the only shard is the sequence: replicas only, no collective on the
-data path) and value = total steps/s over all ranks.
+data path) and value = total steps/s over all ranks.  Launched under torchrun the ranks come
+from the environment; launched plainly (`python bench.py --gpus N`) the script starts its N
+ranks itself, before anything in the parent touches a GPU.
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  Besides the contract keys: `roofline` (the P-update GEMM pair),
+`roofline_step` (the whole step), `cpu_baseline` (fp32 oracle, 1 core), `full_loop` (frames/s of
+ekfvio_step_image: image in, KLT supplies z, update, replenishment), `klt` and `klt_cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 
 
 def dist_setup(n_gpus, backend=None):
@@ -32,6 +39,9 @@ def dist_setup(n_gpus, backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, n_gpus):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch N ranks (torchrun) or none (the script then "
+                         "starts them itself)" % (n_gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
@@ -41,6 +51,26 @@ def dist_setup(n_gpus, backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes, one per device (RANK = LOCAL_RANK = r,
+    seed = rank), rendezvous on 127.0.0.1.  The parent never initialises a GPU; rank 0's JSON line is the output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def barrier(world):
@@ -78,8 +108,8 @@ def result_line(args, world, n_landmarks, elapsed, extra):
 
 
 def selftest_dist(args):
-    """Exercises only the multi-rank plumbing (barrier, max-over-ranks, aggregation) with a
-    synthetic per-rank time; used by the gloo CPU test.  Computes nothing."""
+    """Exercises only the multi-rank plumbing (self-spawned or torchrun ranks, barrier, max-over-ranks, aggregation)
+    with a synthetic per-rank time; used by the gloo CPU tests.  Computes nothing."""
     world, rank, _ = dist_setup(args.gpus, backend="gloo")
     barrier(world)
     elapsed = max_over_ranks(0.5 + 0.25 * rank, world)
@@ -115,6 +145,112 @@ def cpu_baseline(n_landmarks, dt, budget_steps, threads=1):
                                                                         "" if threads == 1 else "s (OpenMP)", el)}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Full loop ("KLT reported separately and inside the full-loop figure"): ekfvio_step_image per frame
+# = frame upload, pyramid, process(dt), KLT seeded by the filter's prediction, update, FAST replenishment.
+def _textured_sequence(frames, dx=-1.4, dy=-0.45):
+    """The reference's 640x480 test image seen by a camera gliding over it: frame i is the image translated by
+    i * (dx, dy) pixels (bilinear, wrap-around) -- a fronto-parallel textured plane under lateral motion."""
+    from PIL import Image
+    base = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "images", "640_480_test_gray.png"))).astype(np.float32)
+    out = []
+    for i in range(frames):
+        sx, sy = i * dx, i * dy
+        ix, iy = int(np.floor(sx)), int(np.floor(sy))
+        fx, fy = sx - ix, sy - iy
+        a = np.roll(base, (iy, ix), axis=(0, 1))
+        b = np.roll(base, (iy, ix + 1), axis=(0, 1))
+        c = np.roll(base, (iy + 1, ix), axis=(0, 1))
+        d = np.roll(base, (iy + 1, ix + 1), axis=(0, 1))
+        img = (1 - fy) * ((1 - fx) * a + fx * b) + fy * ((1 - fx) * c + fx * d)
+        out.append(np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8)))
+    return out
+
+
+def full_loop(n_landmarks, device, frames=40, warm=6):
+    from ekf_vio_amd import EKFVIO, capi
+    K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)  # SURVEY 8(d) config 1
+    imgs = _textured_sequence(warm + frames)
+    # enough corners for N landmarks on this image: the reference defaults (threshold 50, 30 px apart) yield ~90
+    thr, dist = (50, 30) if n_landmarks <= 64 else (20, 12)
+    v = EKFVIO(max_features=n_landmarks, device=device, replenish=1, fast_threshold=thr, min_new_feature_dist=dist)
+    e = v.tc_ekf
+    numeric = 0
+    for i in range(warm):
+        numeric += v.addFrame(i / 30.0, imgs[i], K) == capi.ENUMERIC
+    e.synchronize()
+    n_start = e.num_features
+    t0 = time.perf_counter()
+    for i in range(warm, warm + frames):
+        numeric += v.addFrame(i / 30.0, imgs[i], K) == capi.ENUMERIC
+    e.synchronize()
+    el = time.perf_counter() - t0
+    st = e.get_state()
+    tracked = int((st["del_flag"] == 0).sum())
+    # per-stage device time of the same loop, HIP events on the handle's stream (adds a host wait per stage: not timed above)
+    e.profile(True)
+    for i in range(warm + frames - 8, warm + frames):
+        v.addFrame((i + 100) / 30.0, imgs[i], K)
+    rep = e.profile_report()
+    e.profile(False)
+    stage = {k: 1e3 * x["ms"] / 8 for k, x in rep.items() if x["launches"]}
+    finite = bool(np.isfinite(st["base_mu"]).all() and np.isfinite(st["Sigma"]).all())
+    N = e.num_features
+    e.close()
+    pyr_us, trk_us = stage.get("klt_pyramid", 0.0), stage.get("klt_track", 0.0)
+    # algorithmic bytes of the pyramid build per frame (SURVEY 8(d)): read the frame, write levels 0-3 (8-bit) and
+    # their int16 (dx, dy) derivatives
+    lv = [(640, 480), (320, 240), (160, 120), (80, 60)]
+    pyr_bytes = 640 * 480 + sum(w * h * (1 + 4) for w, h in lv)
+    return {"frames_per_s": frames / el, "ms_per_frame": 1e3 * el / frames, "landmarks": N, "landmarks_at_start": n_start,
+            "landmarks_never_lost": tracked, "numeric_warnings": int(numeric), "state_finite": finite, "frames": frames,
+            "image": "tests/golden/images/640_480_test_gray.png translated by (-1.4, -0.45) px per frame, fx = fy = 500",
+            "what": "ekfvio_step_image per frame: H2D frame, pyramid, process(dt), KLT (z from the tracker), update, replenishment (cfg.replenish=1, FAST threshold %d, %d px apart)" % (thr, dist),
+            "stage_us_per_frame": stage,
+            "klt": {"pyramid_us": pyr_us, "track_us": trk_us, "tracks_per_s": (N / (trk_us * 1e-6)) if trk_us else None,
+                    "pyramid_bytes": pyr_bytes,
+                    "pyramid_gb_per_s": (pyr_bytes / (pyr_us * 1e-6) / 1e9) if pyr_us else None,
+                    "pyramid_frac_of_hbm_peak": (pyr_bytes / (pyr_us * 1e-6) / 1e9 / PEAK_HBM_GBS) if pyr_us else None,
+                    "note": "event-bracketed stage times (include ~5 us of launch gaps per stage); the pyramid is 4 launches over 0.4 MB in / 2.1 MB out: latency bound, "
+                            "not HBM bound; the tracker is one wavefront per landmark, latency bound on its Gauss-Newton chain"}}
+
+
+def klt_cpu_baseline(n_points):
+    """the oracle's pyramidal LK (oracle/klt_oracle.cpp, OpenCV 3.x calcOpticalFlowPyrLK restated), 1 core:
+    pyramids + Scharr derivatives of both frames, then n_points tracks from one frame of the sequence into the next."""
+    from oracle import KltFrame, klt_track, set_threads
+    set_threads(1)
+    a, b = _textured_sequence(2)
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(40, 600, n_points), rng.uniform(40, 440, n_points)], axis=1).astype(np.float32)
+    t0 = time.perf_counter()
+    A, B = KltFrame(a), KltFrame(b)
+    t1 = time.perf_counter()
+    reps = 0
+    while True:
+        nxt, st, _ = klt_track(A, B, pts, pts.copy())
+        reps += 1
+        if time.perf_counter() - t1 > 2.0 or reps >= 20:
+            break
+    t2 = time.perf_counter()
+    return {"pyramid_ms_per_frame": 1e3 * (t1 - t0) / 2, "track_ms": 1e3 * (t2 - t1) / reps, "points": n_points,
+            "tracks_per_s": n_points * reps / (t2 - t1), "tracked_ok": int(st.sum()), "cores": 1, "kind": "port",
+            "sample": "2 pyramids + %d x %d tracks, window 21, levels 0-3, 30 it / 0.01 (KLTTracker.cpp:61-64)" % (reps, n_points)}
+
+
+def step_flops(N):
+    """Algorithmic flops the step executes (dense form of the update, structured predict), DESIGN.md section 4."""
+    n, m = 22 + 3 * N, 2 * N
+    m_pad = ((m + 63) // 64) * 64
+    joseph = 2.0 * n * (n + 1) * m_pad + 2.0 * n * n * m_pad      # T = Sigma - K W (+ the K*y column); Sigma' = T + G K^T
+    gain = 1.0 * n * m_pad * m_pad                               # K = Y L^-1, triangular operand
+    sweep = m_pad ** 3 / 3.0 + (n + m_pad / 2.0) * m_pad * m_pad  # Cholesky + the two augmented row blocks
+    predict = 4.0 * n * (358.0 + 36.0 * N)
+    return {"joseph_gemms": joseph, "gain_gemm": gain, "cholesky_sweep": sweep, "structured_predict": predict,
+            "total": joseph + gain + sweep + predict,
+            "north_star_dense_form": 4.0 * n ** 3 + m ** 3 / 3.0 + 4.0 * n * m * m + 4.0 * n * n * m}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,10 +259,13 @@ def main():
     ap.add_argument("--landmarks", type=int, default=256)
     ap.add_argument("--predict", choices=["structured", "dense"], default="structured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-loop", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto ~10-30 s)")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--selftest-dist", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))  # before any GPU call in this process
     if args.selftest_dist:
         return selftest_dist(args)
 
@@ -158,14 +297,14 @@ def main():
     barrier(world)
     t0 = time.perf_counter()
     g.run_uploaded(args.warmup, args.steps, dt)
-    g.synchronize()
+    numeric = g.synchronize()
     torch.cuda.synchronize()
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
     md, ma = g.checkSigma()
     st_ok = bool(np.isfinite(g.base_mu).all() and md >= 0)
 
-    extra = {"state_finite_and_psd_diag": st_ok}
+    extra = {"state_finite_and_psd_diag": st_ok, "numeric_warning_in_timed_run": bool(numeric == capi.ENUMERIC)}
     if rank == 0:
         # per-kernel-class device time with HIP events on the handle's stream
         g.profile(True)
@@ -180,19 +319,36 @@ def main():
         # the timed region (the per-class event brackets above run eagerly and include host launch gaps).
         avg_us, flops_per_launch = g.profile_update_gemms(50)
         achieved = flops_per_launch / (avg_us * 1e-6) / 1e12
-        extra["roofline"] = {"bound": "mfma", "kernel": "gemm16_kernel<BM,2,1|2> (P-update GEMMs: Sigma - K W, T + G K^T; BM x 64 tiles, BM chosen by shape)",
+        extra["roofline"] = {"bound": "mfma", "kernel": "P-update GEMM pair (Sigma - K W, T + G K^T), tile kernel chosen by shape",
                              "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                              "flops_per_launch": flops_per_launch, "avg_launch_us": avg_us,
                              "shape": {"M": n, "N": n, "K": m_pad}}
-        # HBM-side traffic of the same kernels comes from separate rocprofv3 --pmc passes (bench.py
-        # cannot collect PMCs itself); the committed summary is quoted when the workload matches
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_n256.json")  # committed summary of the two --pmc passes
-        if N == 256 and os.path.exists(pmc):
-            pj = json.load(open(pmc))
-            extra["roofline"]["traffic"] = pj["p_update_gemm_traffic_bytes_per_launch"]
-            extra["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)"
-            extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
+        # HBM-side traffic and MFMA-busy counters of the same kernels come from separate rocprofv3 --pmc passes
+        # (bench.py cannot collect PMCs itself); the committed summaries are quoted when the workload matches
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_n256.json" % tag)
+            if N == 256 and os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if "p_update_gemm_traffic_bytes_per_launch" in pj:
+                    extra["roofline"]["traffic"] = pj["p_update_gemm_traffic_bytes_per_launch"]
+                    extra["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)" % tag
+                    extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
+                    break
+        mf = os.path.join(ROOT, "profiles", "r02_pmc_mfma_n256.json")
+        if N == 256 and os.path.exists(mf):
+            mj = json.load(open(mf))
+            extra["roofline"]["mfma_counters"] = mj.get("p_update_gemms")
+            extra["roofline"]["mfma_counters_source"] = "profiles/r02_pmc_mfma_n256.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...)"
+        # The whole step against the same peak: what fraction of the chip's fp32 matrix rate one filter step uses
+        fl = step_flops(N)
+        ms_step = 1e3 * elapsed / args.steps
+        extra["roofline_step"] = {"bound": "mfma", "flops_per_step": fl["total"], "breakdown": {k: fl[k] for k in ("joseph_gemms", "gain_gemm", "cholesky_sweep", "structured_predict")},
+                                  "achieved": fl["total"] / (ms_step * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fl["total"] / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                  "north_star_dense_form_flops": fl["north_star_dense_form"],
+                                  "note": "executed algorithmic flops (dense-form update on the padded shape, structured predict) / ms_per_step; the north-star dense form "
+                                          "(4n^3 predict + Joseph expansion) is listed for reference and is NOT what runs: the predict exploits F's sparsity"}
         # PCIe-inclusive rate (never `value`): the per-call boundary with host-resident measurements,
         # one ekfvio_process + one synchronising ekfvio_update per step
         nh = min(100, len(fr))
@@ -216,14 +372,23 @@ def main():
         except Exception as ex:  # diagnostic extra, never fatal
             extra["roofline_stress_shape"] = {"error": str(ex)}
         extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
+    g.close()
+    if rank == 0:
+        if world == 1 and not args.no_full_loop:
+            try:
+                extra["full_loop"] = {"n64": full_loop(64, local), "n256": full_loop(256, local)}
+                extra["klt"] = extra["full_loop"]["n256"].pop("klt")
+                extra["full_loop"]["n64"].pop("klt")
+            except Exception as ex:  # reported, never fatal for the headline metric
+                extra["full_loop"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps or max(3, int(round(60.0 * (256.0 / N) ** 3)))
             extra["cpu_baseline"] = cpu_baseline(N, dt, steps)
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             if ncpu > 1:
                 extra["cpu_baseline_all_cores"] = cpu_baseline(N, dt, max(3, steps // 2), threads=min(ncpu, 64))
+            extra["klt_cpu_baseline"] = klt_cpu_baseline(256)
         print(json.dumps(result_line(args, world, N, elapsed, extra)))
-    g.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

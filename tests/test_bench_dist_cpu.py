@@ -33,3 +33,23 @@ def test_single_rank_selftest_line_has_contract_keys():
               "vs_baseline", "dtype", "data", "config"):
         assert k in r
     assert r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]
+
+
+def test_gpus_flag_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torchrun around it: the script starts its two ranks itself (before anything
+    touches a GPU) and rank 0 reports the whole job."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "5",
+                          "--selftest-dist"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and abs(r["value"] - 2 * 100 / 0.75) < 1e-6 and r["config"]["sequences"] == 2
+
+
+def test_gpus_flag_that_disagrees_with_the_launcher_fails_loudly():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-dist"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
