@@ -149,28 +149,18 @@ def cpu_baseline(n_landmarks, dt, budget_steps, threads=1):
 # Full loop ("KLT reported separately and inside the full-loop figure"): ekfvio_step_image per frame
 # = frame upload, pyramid, process(dt), KLT seeded by the filter's prediction, update, FAST replenishment.
 def _textured_sequence(frames, dx=-1.4, dy=-0.45):
-    """The reference's 640x480 test image seen by a camera gliding over it: frame i is the image translated by
-    i * (dx, dy) pixels (bilinear, wrap-around) -- a fronto-parallel textured plane under lateral motion."""
+    """The reference's 640x480 test image seen by a camera gliding over it (ekf_vio_amd.sim.translated_sequence)."""
     from PIL import Image
-    base = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "images", "640_480_test_gray.png"))).astype(np.float32)
-    out = []
-    for i in range(frames):
-        sx, sy = i * dx, i * dy
-        ix, iy = int(np.floor(sx)), int(np.floor(sy))
-        fx, fy = sx - ix, sy - iy
-        a = np.roll(base, (iy, ix), axis=(0, 1))
-        b = np.roll(base, (iy, ix + 1), axis=(0, 1))
-        c = np.roll(base, (iy + 1, ix), axis=(0, 1))
-        d = np.roll(base, (iy + 1, ix + 1), axis=(0, 1))
-        img = (1 - fy) * ((1 - fx) * a + fx * b) + fy * ((1 - fx) * c + fx * d)
-        out.append(np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8)))
-    return out
+    from ekf_vio_amd.sim import translated_sequence
+    base = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "images", "640_480_test_gray.png")))
+    return translated_sequence(base, frames, dx, dy)
 
 
 def full_loop(n_landmarks, device, frames=40, warm=6):
     from ekf_vio_amd import EKFVIO, capi
     K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)  # SURVEY 8(d) config 1
-    imgs = _textured_sequence(warm + frames)
+    prof = 8
+    imgs = _textured_sequence(warm + frames + prof)
     # enough corners for N landmarks on this image: the reference defaults (threshold 50, 30 px apart) yield ~90
     thr, dist = (50, 30) if n_landmarks <= 64 else (20, 12)
     v = EKFVIO(max_features=n_landmarks, device=device, replenish=1, fast_threshold=thr, min_new_feature_dist=dist)
@@ -189,11 +179,11 @@ def full_loop(n_landmarks, device, frames=40, warm=6):
     tracked = int((st["del_flag"] == 0).sum())
     # per-stage device time of the same loop, HIP events on the handle's stream (adds a host wait per stage: not timed above)
     e.profile(True)
-    for i in range(warm + frames - 8, warm + frames):
-        v.addFrame((i + 100) / 30.0, imgs[i], K)
+    for i in range(warm + frames, warm + frames + prof):  # the sequence simply continues
+        v.addFrame(i / 30.0, imgs[i], K)
     rep = e.profile_report()
     e.profile(False)
-    stage = {k: 1e3 * x["ms"] / 8 for k, x in rep.items() if x["launches"]}
+    stage = {k: 1e3 * x["ms"] / prof for k, x in rep.items() if x["launches"]}
     finite = bool(np.isfinite(st["base_mu"]).all() and np.isfinite(st["Sigma"]).all())
     N = e.num_features
     e.close()
@@ -282,7 +272,8 @@ def main():
     g = TightlyCoupledEKF(max_features=N, device=local, predict_mode=mode)
     g.addNewFeatures(sc.initial_features())
     total = args.warmup + args.steps
-    n_frames = min(total, 4096)  # longer runs wrap around the uploaded sequence
+    extra_frames = args.profile_steps + 100  # the profiled steps and the per-call (PCIe-inclusive) loop continue the sequence
+    n_frames = min(total, 4096) + extra_frames  # longer runs wrap around the uploaded sequence
     fr = list(sc.frames(n_frames))
     g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
     dt = sc.dt
@@ -308,7 +299,7 @@ def main():
     if rank == 0:
         # per-kernel-class device time with HIP events on the handle's stream
         g.profile(True)
-        g.run_uploaded(0, args.profile_steps, dt)
+        g.run_uploaded(total, args.profile_steps, dt)
         g.synchronize()
         rep = g.profile_report()
         g.profile(False)
@@ -351,9 +342,9 @@ def main():
                                           "(4n^3 predict + Joseph expansion) is listed for reference and is NOT what runs: the predict exploits F's sparsity"}
         # PCIe-inclusive rate (never `value`): the per-call boundary with host-resident measurements,
         # one ekfvio_process + one synchronising ekfvio_update per step
-        nh = min(100, len(fr))
+        nh = 100
         th = time.perf_counter()
-        for z_h, R_h, p_h in fr[:nh]:
+        for z_h, R_h, p_h in fr[-nh:]:
             g.process(dt)
             g.updateWithFeaturePositions(z_h, R_h, p_h)
         g.synchronize()

@@ -144,6 +144,7 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     HIPC(f, dev_alloc(f->stream, &f->Saug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
+    HIPC(f, dev_alloc(f->stream, &f->Lsign, (size_t)(f->m_cap / 64 > 256 ? f->m_cap / 64 : 256)));  // 256: the raw-solve test hook goes up to m = 16384
     HIPC(f, dev_alloc(f->stream, &f->sweep_sync, 2 * (size_t)(f->m_cap / 64 > 128 ? f->m_cap / 64 : 128) + 4));
     {
         hipDeviceProp_t prop;
@@ -200,7 +201,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     (void)hipSetDevice(f->device);
     if (f->stream) (void)hipStreamSynchronize(f->stream);
     void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
-                    f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Km, f->sweep_sync, f->sweep_dbg,
+                    f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Lsign, f->Km, f->sweep_sync, f->sweep_dbg,
                     f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -798,7 +799,13 @@ int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const 
     HIPC(f, dev_alloc(f->stream, &dW, (size_t)rp * mp));
     HIPC(f, hipMemcpyAsync(dS, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, f->stream));
     launch_chol_sweep(f, dS, dL, dLi, mp, rp, ld);
-    launch_gain_from_sweep(f, dL, mp, rp, ld, nrhs, dK, dW, rp, 1);
+    // one step of residual refinement against L, unless a block went through the U S U^T path (K L = Y S then, not Y)
+    std::vector<unsigned long long> hsign(mp / 64);
+    HIPC(f, hipMemcpyAsync(hsign.data(), f->Lsign, sizeof(unsigned long long) * hsign.size(), hipMemcpyDeviceToHost, f->stream));
+    HIPC(f, hipStreamSynchronize(f->stream));
+    int refine = 1;
+    for (unsigned long long v : hsign) refine &= (v == 0ull);
+    launch_gain_from_sweep(f, dL, mp, rp, ld, nrhs, dK, dW, rp, refine);
     std::vector<float> hl(hs.size()), hk((size_t)rp * mp);
     HIPC(f, hipMemcpyAsync(hl.data(), dL, sizeof(float) * hl.size(), hipMemcpyDeviceToHost, f->stream));
     HIPC(f, hipMemcpyAsync(hk.data(), dK, sizeof(float) * hk.size(), hipMemcpyDeviceToHost, f->stream));

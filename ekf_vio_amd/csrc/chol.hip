@@ -25,6 +25,18 @@
 // state error on the first, ill-conditioned update).
 // The 64x64x64 trailing products run on v_mfma_f32_32x32x2_f32.  LDS tiles are column-major
 // with a row stride of 65 floats: conflict-free for both operand orientations.
+//
+// A numerically indefinite A.  The reference's SimplicialLDLT carries negative pivots along (only an exactly zero one
+// is a NumericalIssue), and with its tiny measurement noise (1e-5 px^2 / fx^2) or many landmarks on the raw prior the
+// fp32 S really is indefinite (cond(S) ~ 1e7 .. 1e12).  A Cholesky would have to clamp such a pivot and destroy the
+// gain.  So a diagonal tile whose fast factorisation meets a non-positive pivot is factored again by a slow, plain
+// path as A = U S U^T, S = diag(+-1), U lower triangular with U_cc = sign_c sqrt|d_c| (column c of the eliminated tile
+// scaled by rsqrt|d_c|): everything downstream keeps its form -- the substitutions use U and the inverses of its 16x16
+// diagonal blocks, trailing updates become A_ij -= U_ik S_k U_jk^T (the sign of column c applied to the left operand as
+// it is read, from a 64-bit mask per block column), and the gain K = Y S U^-1 gets S through the identity rows, whose
+// panel blocks are stored with the column signs applied.  With no negative pivot every mask is zero and every branch
+// on it is a scalar compare: the fast path's instruction streams are untouched.  The pivot flag (info bit 0) is still
+// raised, as a warning that S was not positive definite in fp32.
 #include "common.h"
 
 #include <type_traits>
@@ -103,6 +115,18 @@ __device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G
 #endif
     }
 }
+// a panel block of the identity rows with the column signs of its block column applied (the gain GEMM K = Y S U^-1 takes
+// S from here; `neg` is zero unless the block had negative pivots)
+__device__ __forceinline__ void store_tile_signed(const float* T, float* __restrict__ G, int ld, int tid, unsigned long long neg) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int e = tid + it * 256;
+        const int c = e >> 4, r4 = (e & 15) * 4;
+        const float* t = T + c * PLD + r4;
+        const float sg = ((neg >> c) & 1ull) ? -1.f : 1.f;
+        *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) = make_float4(sg * t[0], sg * t[1], sg * t[2], sg * t[3]);
+    }
+}
 // lower triangle of a diagonal tile; the strict upper triangle is written as zero
 __device__ __forceinline__ void store_tile_lower(const float* T, float* __restrict__ G, int ld, int tid) {
 #pragma unroll
@@ -148,6 +172,25 @@ __device__ __forceinline__ f32x16 mma64(const float* As, int a_si, int a_sq, con
 #pragma unroll 8
     for (int q = 0; q < PB; q += 2) {
         const float a = ap[q * a_sq];
+        const float b = bp[q * b_sq];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// The same product with the column signs of an indefinite block applied to A's k index (bit q of `neg` set: column q
+// of the panel belongs to a negative pivot): sum_q s_q A(i,q) B(j,q).  Rare path (see the header).
+__device__ __forceinline__ f32x16 mma64_signed(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int wr,
+                                               int wc, int lane, unsigned long long neg) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+    const float* ap = As + (wr * 32 + li) * a_si + lk * a_sq;
+    const float* bp = Bs + (wc * 32 + li) * b_sj + lk * b_sq;
+#pragma unroll 8
+    for (int q = 0; q < PB; q += 2) {
+        float a = ap[q * a_sq];
+        if ((neg >> (q + lk)) & 1ull) a = -a;
         const float b = bp[q * b_sq];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0);
     }
@@ -415,8 +458,36 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
     });
     // the strict upper triangle still holds the symmetric input: store_tile_lower drops it
     POTRF_STAMP(10);
-    if (wave == 0) bad = __ballot(!(A[lane * PLD + lane] > 2e-10f)) != 0ull;
+    // every wavefront looks at the 64 diagonal entries itself: the answer is uniform over the workgroup without a barrier
+    bad = __ballot(!(A[lane * PLD + lane] > 2e-10f)) != 0ull;
     return bad;
+}
+
+// Slow path for a tile the fast factorisation flagged (see the header): A = U S U^T by plain right-looking column
+// elimination on wavefront 0 (one matrix row per lane, the tile in LDS), then the four 16x16 inverses of U's diagonal
+// blocks, one per wavefront.  A must hold the lower triangle of the ORIGINAL tile again (callers rebuild it).  Returns
+// the mask of negative pivots (uniform over the workgroup).  A pivot of magnitude below 1e-20 is treated as +-1e-20.
+__device__ __forceinline__ unsigned long long potrf64_signed(float* A, float* Tinv, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    if (wave == 0) {
+        for (int k = 0; k < PB; k++) {
+            const float d = A[k * PLD + k];
+            const float inv = __builtin_amdgcn_rsqf(fmaxf(fabsf(d), 1e-20f));
+            const float u = (lane >= k) ? A[k * PLD + lane] * inv : 0.f;   // column k of U (U_kk = sign * sqrt|d|)
+            if (lane >= k) A[k * PLD + lane] = u;
+            const float su = (d < 0.f) ? -u : u;
+            for (int j = k + 1; j < PB; j++) {
+                const float uj = lane_bcast(u, j);
+                if (lane >= j) A[j * PLD + lane] = __builtin_fmaf(-su, uj, A[j * PLD + lane]);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long neg = __ballot(A[lane * PLD + lane] < 0.f);
+    potrf_inverse16(A, Tinv, wave, lane);
+    __syncthreads();
+    return neg;
 }
 
 // Diagnostic twin of potrf64_kernel: same work, s_memtime stamps after every phase.
@@ -438,16 +509,25 @@ __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restr
 
 // Factor the first diagonal block (step "-1" of the sweep).
 __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
-                                                      int ldl, float* __restrict__ Linv, int* info) {
+                                                      int ldl, float* __restrict__ Linv, int* info, unsigned long long* Lsign) {
     __shared__ __attribute__((aligned(16))) float A[PB * PLD];
     __shared__ float Tinv[INV_LDS];
     const int tid = threadIdx.x;
     load_tile(A, S, lds, tid);
     __syncthreads();
     const bool bad = potrf64_lds(A, Tinv, tid);
+    unsigned long long neg = 0ull;
+    if (bad) {  // workgroup-uniform
+        __syncthreads();
+        load_tile(A, S, lds, tid);
+        neg = potrf64_signed(A, Tinv, tid);
+    }
     store_tile_lower(A, L, ldl, tid);
     store_inv(Tinv, Linv, tid);
-    if (bad && tid == 0) atomicOr(info, 1);
+    if (tid == 0) {
+        Lsign[0] = neg;
+        if (bad) atomicOr(info, 1);
+    }
 }
 
 #include "gather_body.inc"
@@ -458,7 +538,7 @@ __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ 
 // latency-bound and runs 2x longer when its compute unit is shared, so the launch asks for more than half a compute
 // unit's LDS per workgroup (EKF_GATHER_POTRF_LDS): one workgroup per compute unit, the chain has its own.
 __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float* __restrict__ L, int ldl, float* __restrict__ Linv,
-                                                           int* info, long long* dbg) {
+                                                           int* info, unsigned long long* Lsign, long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
     const int tid = threadIdx.x;
 #define GSTAMP_(slot)                                                                               \
@@ -503,10 +583,23 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
     __syncthreads();
     GSTAMP_(1);
     const bool bad = potrf64_lds(A, Tinv, tid);
+    unsigned long long neg = 0ull;
+    if (bad) {  // workgroup-uniform, rare: the tile is gathered again (its loads were consumed) and factored as U S U^T
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 16; ps++) {
+            const int r = (tid >> 6) + 4 * ps;
+            A[c * PLD + r] = gather_a_elem(ga.P[(size_t)ir[ps] * ga.ld + sc], r, c, m, rd[ps], ro[ps]);
+        }
+        neg = potrf64_signed(A, Tinv, tid);
+    }
     GSTAMP_(2);
     store_tile_lower(A, L, ldl, tid);
     store_inv(Tinv, Linv, tid);
-    if (bad && tid == 0) atomicOr(info, 1);
+    if (tid == 0) {
+        Lsign[0] = neg;
+        if (bad) atomicOr(info, 1);
+    }
     GSTAMP_(3);
 #undef GSTAMP_
 }
@@ -522,7 +615,7 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
 template <bool SOLVE>
 __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
                                                         float* __restrict__ Linv, int k, int mb, int idb0, int* info,
-                                                        long long* dbg) {
+                                                        unsigned long long* Lsign, long long* dbg) {
     // diagnostic phase stamps of the chain workgroup (scripts/chol_step_stamps.py); dbg is null in production
 #define CSTAMP(slot)                                                                                         \
     do {                                                                                                     \
@@ -554,6 +647,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         if (i >= idb0 && i - idb0 > k) return;  // identity block row: block (i,k) is still zero
     }
 
+    // negative pivots of block column k (zero unless diagonal tile k went through the U S U^T path): a scalar load
+    const unsigned long long neg = Lsign[k];
     if (SOLVE) {
         load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
         load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
@@ -567,7 +662,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
             tri_solve_fwd(Ti, Tl, Tinv, wave, lane, (dbg && blockIdx.x == 0) ? dbg + 960 + 4 * k : nullptr);
         __syncthreads();
         CSTAMP(2);
-        if (j == k + 1) store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+        if (j == k + 1) {
+            float* dst = L + (size_t)k * PB * ldl + (size_t)i * PB;
+            if (neg != 0ull && i >= idb0) store_tile_signed(Ti, dst, ldl, tid, neg);  // identity rows carry S into the gain
+            else store_tile(Ti, dst, ldl, tid);
+        }
     } else {
         load_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
         if (i != j) load_tile(Tj, L + (size_t)k * PB * ldl + (size_t)j * PB, ldl, tid);
@@ -597,7 +696,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
 #endif
     CSTAMP(7);
-    const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
+    const f32x16 up = (neg == 0ull) ? mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane)
+                                    : mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg);
     CSTAMP(6);
     if (chain) {
         // next diagonal tile: update into LDS and factor it now (look-ahead)
@@ -618,10 +718,23 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         __syncthreads();
         CSTAMP(3);
         const bool bad = potrf64_lds(Tl, Tinv, tid);
+        unsigned long long neg1 = 0ull;
+        if (bad) {  // workgroup-uniform, rare: the updated tile is formed again and factored as U S U^T
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                Tl[c * PLD + r] = Sij[(size_t)c * lds + r] - up[q];
+            }
+            neg1 = potrf64_signed(Tl, Tinv, tid);
+        }
         CSTAMP(4);
         store_tile_lower(Tl, L + (size_t)j * PB * ldl + (size_t)i * PB, ldl, tid);
         store_inv(Tinv, Linv + (size_t)(k + 1) * PB * PB, tid);
-        if (bad && tid == 0) atomicOr(info, 1);
+        if (tid == 0) {
+            Lsign[k + 1] = neg1;
+            if (bad) atomicOr(info, 1);
+        }
         CSTAMP(5);
     } else {
         // read all sixteen targets, then write them: written as sixteen `-=` the compiler cannot rule out that a store
@@ -642,8 +755,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
 
 // Block column k of the panel: L_ik = A_ik L_kk^-T for the row blocks below the diagonal (A rows k+1 .. mb-1, `na` of
 // them; na = 0 for the last block column) and the extra row blocks (X, I).
+// sign_irows: the panel blocks of the identity rows are stored with the block column's signs applied (what the gain GEMM
+// reads); off in the split sweep, whose update launches read the stored blocks back as operands (launch_chol_sweep).
 __global__ __launch_bounds__(256) void chol_panel_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
-                                                         int ldl, const float* __restrict__ Linv, int k, int mb, int na, int idb0) {
+                                                         int ldl, const float* __restrict__ Linv, int k, int mb, int na, int idb0,
+                                                         const unsigned long long* __restrict__ Lsign, int sign_irows) {
     __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];
     __shared__ __attribute__((aligned(16))) float Tl[PB * PLD];
     __shared__ float Tinv[INV_LDS];
@@ -657,7 +773,25 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const float* __restrict
     __syncthreads();
     tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
     __syncthreads();
-    store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+    const unsigned long long neg = Lsign[k];
+    if (sign_irows && neg != 0ull && i >= idb0) store_tile_signed(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid, neg);
+    else store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
+}
+
+// Split sweep only: its panel blocks are stored unsigned (they are read back as operands), so the column signs of the
+// identity rows' blocks (L^-T, what the gain GEMM multiplies by) are applied afterwards, one block column per
+// blockIdx.y; a block column without negative pivots returns at once.
+__global__ __launch_bounds__(256) void sign_irows_kernel(float* __restrict__ L, int ldl, int row0, int rows,
+                                                         const unsigned long long* __restrict__ Lsign) {
+    const unsigned long long neg = Lsign[blockIdx.y];
+    if (neg == 0ull) return;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    for (int c = 0; c < PB; c++)
+        if ((neg >> c) & 1ull) {
+            float* p = L + (size_t)(blockIdx.y * PB + c) * ldl + row0 + r;
+            *p = -*p;
+        }
 }
 
 
@@ -939,7 +1073,7 @@ void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_o
     if (m_on_device) ga.m_dev = f->info + 2;
     const int nb2 = (m_pad / 64) * (f->ldp / 64);  // 64x64 transposing tiles of Wt
     hipLaunchKernelGGL(gather_potrf_kernel, dim3(1 + ga.nb1 + nb2), dim3(256), EKF_GATHER_POTRF_LDS, f->stream, ga, f->Laug, f->ld_aug,
-                       f->Linv, f->info, f->sweep_dbg);
+                       f->Linv, f->info, f->Lsign, f->sweep_dbg);
 }
 
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done) {
@@ -958,22 +1092,28 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
                            idb0, f->info, f->sweep_sync, f->sweep_dbg);
         return;
     }
-    if (!first_tile_done) hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info);
+    if (!first_tile_done)
+        hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     // many tiles per step: panel blocks once per step in a launch of their own instead of twice per tile
     const bool split = mb >= EKF_SWEEP_SPLIT_MB;
     for (int k = 0; k + 1 < mb; k++) {
         const int r = mb - 1 - k;
         const dim3 grid(r * (r + 1) / 2 + rb * r);
         if (split) {
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(r + rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, r, idb0);
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(r + rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, r, idb0,
+                               f->Lsign, 0);
             hipLaunchKernelGGL(chol_step_kernel<false>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
-                               f->sweep_dbg);
+                               f->Lsign, f->sweep_dbg);
         } else {
             hipLaunchKernelGGL(chol_step_kernel<true>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
-                               f->sweep_dbg);
+                               f->Lsign, f->sweep_dbg);
         }
     }
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0, f->Lsign,
+                       split ? 0 : 1);
+    if (split)  // the stored identity-row blocks were operands until now: their column signs go on last
+        hipLaunchKernelGGL(sign_irows_kernel, dim3((m_pad + 255) / 256, mb), dim3(256), 0, f->stream, Laug, ld, idb0 * PB, m_pad,
+                           f->Lsign);
 }
 
 // K = X A^-1 = Y L^-1 with Y = X L^-T and L^-T (both from the sweep): one MFMA GEMM that

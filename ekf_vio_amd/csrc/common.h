@@ -95,6 +95,7 @@ struct ekfvio_filter {
     float* Laug = nullptr;
     int ld_aug = 0;            // m_cap + ldp + m_cap
     float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
+    unsigned long long* Lsign = nullptr;  // [>= m_cap/64] per block column: mask of negative pivots (0 = positive definite block)
     int* sweep_sync = nullptr; // [2*m_cap/64 + 4] ready/done counters + abort flag of the persistent sweep
     int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)

@@ -6,11 +6,24 @@
 // final odometry next to the ground truth, the checkSigma numbers and the step rate.
 // Usage: ekfvio_replay [landmarks=256] [frames=300] [seed=0] [dt=0.0333333]
 //        ekfvio_replay --print-config [params.yaml]   (no GPU work: the node's parameter file -> ekfvio_config as JSON)
+//        ekfvio_replay --records <dir> [--out <dir>] [--params params.yaml] [--device n]
+//
+// --records replays what the node's two subscriptions deliver (EKFVIO.cpp:69-81) and writes what its two publishers
+// send (EKFVIO.cpp:444-518), with no ROS in between.  <dir>/records.txt holds one record per line, in arrival order:
+//     image <stamp> <file> <K0> ... <K8>      8-bit binary PGM (P5), intrinsics row-major as in sensor_msgs/CameraInfo.K
+//     imu   <stamp> <gx> <gy> <gz> <ax> <ay> <az>
+// Every image record goes through EKFVIO::addFrame (frame ingest, process(dt), KLT, update, FAST replenishment:
+// cfg.replenish = 1); after it one odometry record and one point-cloud record are appended to
+//     <out>/odom.txt     stamp px py pz qw qx qy qz vx vy vz wx wy wz numeric_ok
+//     <out>/points.txt   "cloud <stamp> <n>" followed by n lines "x y z intensity"
+// (floats printed with %.9g: exact).  IMU records go to imu_callback, a logging stub in the reference.
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 
 #include "ekfvio.hpp"
 
@@ -74,8 +87,139 @@ static int print_config(const char* path) {
     }
 }
 
+
+// 8-bit binary PGM ("P5", optional comments, maxval 255)
+static bool read_pgm(const std::string& path, std::vector<uint8_t>& px, int& w, int& h) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return false;
+    std::string magic;
+    in >> magic;
+    if (magic != "P5") return false;
+    int vals[3], got = 0;
+    while (got < 3) {
+        int c = in.peek();
+        if (c == '#') {
+            std::string skip;
+            std::getline(in, skip);
+        } else if (std::isspace(c)) {
+            in.get();
+        } else if (!(in >> vals[got++])) {
+            return false;
+        }
+    }
+    in.get();  // the single whitespace byte behind maxval
+    w = vals[0];
+    h = vals[1];
+    if (w < 1 || h < 1 || vals[2] != 255) return false;
+    px.resize((size_t)w * h);
+    in.read(reinterpret_cast<char*>(px.data()), (std::streamsize)px.size());
+    return (size_t)in.gcount() == px.size();
+}
+
+static int replay_records(const std::string& dir, const std::string& out_dir, const char* params_path, int device) {
+    try {
+        ekfvio::Params p = params_path ? ekfvio::Params::fromFile(params_path) : ekfvio::Params();
+        if (!params_path) p.cfg.inverse_image_scale = 1;  // no parameter file: frames are used as recorded
+        p.cfg.replenish = 1;                              // addFrame runs replenishFeatures itself (EKFVIO.cpp:154, :172)
+        std::ifstream rec(dir + "/records.txt");
+        if (!rec) throw ekfvio::Error(EKFVIO_EINVAL, "cannot open " + dir + "/records.txt");
+        // the pyramid buffers are sized by the first image
+        std::vector<uint8_t> px;
+        int w = 0, h = 0;
+        {
+            std::ifstream scan(dir + "/records.txt");
+            std::string line;
+            while (std::getline(scan, line)) {
+                std::istringstream ls(line);
+                std::string kind, file;
+                double stamp;
+                if ((ls >> kind >> stamp >> file) && kind == "image") {
+                    if (!read_pgm(dir + "/" + file, px, w, h)) throw ekfvio::Error(EKFVIO_EINVAL, "cannot read " + file);
+                    break;
+                }
+            }
+        }
+        if (w > 0) {
+            p.cfg.max_image_width = w;
+            p.cfg.max_image_height = h;
+        }
+        ekfvio::EKFVIO node(p, device);
+        FILE* fo = std::fopen((out_dir + "/odom.txt").c_str(), "w");
+        FILE* fp = std::fopen((out_dir + "/points.txt").c_str(), "w");
+        if (!fo || !fp) throw ekfvio::Error(EKFVIO_EINVAL, "cannot write into " + out_dir);
+        std::string line;
+        int images = 0, imus = 0, lineno = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::getline(rec, line)) {
+            lineno++;
+            std::istringstream ls(line);
+            std::string kind;
+            if (!(ls >> kind) || kind[0] == '#') continue;
+            double stamp;
+            if (!(ls >> stamp)) throw ekfvio::Error(EKFVIO_EINVAL, "records.txt line " + std::to_string(lineno) + ": no stamp");
+            if (kind == "imu") {
+                ekfvio::Vector3f g, a;
+                if (!(ls >> g[0] >> g[1] >> g[2] >> a[0] >> a[1] >> a[2]))
+                    throw ekfvio::Error(EKFVIO_EINVAL, "records.txt line " + std::to_string(lineno) + ": imu needs 6 numbers");
+                node.imu_callback(stamp, g, a);
+                imus++;
+            } else if (kind == "image") {
+                std::string file;
+                ekfvio::Frame f;
+                ls >> file;
+                for (int i = 0; i < 9; i++)
+                    if (!(ls >> f.K[i])) throw ekfvio::Error(EKFVIO_EINVAL, "records.txt line " + std::to_string(lineno) + ": image needs a file and K (9 numbers)");
+                int fw, fh;
+                if (!read_pgm(dir + "/" + file, px, fw, fh)) throw ekfvio::Error(EKFVIO_EINVAL, "cannot read " + file);
+                f.img = px.data();
+                f.cols = fw;
+                f.rows = fh;
+                f.step = fw;
+                f.t = stamp;
+                const bool ok = node.addFrame(f);
+                const ekfvio::Odometry od = node.odometry();     // publishOdometry (EKFVIO.cpp:444-477)
+                const ekfvio::PointCloud pc = node.points();     // publishPoints   (EKFVIO.cpp:479-518)
+                std::fprintf(fo, "%.9f %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d\n", od.stamp, od.position[0],
+                             od.position[1], od.position[2], od.orientation_wxyz[0], od.orientation_wxyz[1], od.orientation_wxyz[2],
+                             od.orientation_wxyz[3], od.linear[0], od.linear[1], od.linear[2], od.angular[0], od.angular[1],
+                             od.angular[2], (int)ok);
+                std::fprintf(fp, "cloud %.9f %zu\n", pc.stamp, pc.points.size());
+                for (size_t i = 0; i < pc.points.size(); i++)
+                    std::fprintf(fp, "%.9g %.9g %.9g %.9g\n", pc.points[i][0], pc.points[i][1], pc.points[i][2], pc.intensity[i]);
+                images++;
+            } else {
+                throw ekfvio::Error(EKFVIO_EINVAL, "records.txt line " + std::to_string(lineno) + ": unknown record kind " + kind);
+            }
+        }
+        std::fclose(fo);
+        std::fclose(fp);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("records: %d images, %d imu; %d landmarks; %.1f frames/s (file reading included)\n", images, imus,
+                    node.tc_ekf.numFeatures(), images / el);
+        return 0;
+    } catch (const ekfvio::Error& e) {
+        std::fprintf(stderr, "ekfvio error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && std::strcmp(argv[1], "--print-config") == 0) return print_config(argc > 2 ? argv[2] : nullptr);
+    if (argc > 2 && std::strcmp(argv[1], "--records") == 0) {
+        std::string dir = argv[2], out = argv[2];
+        const char* params = nullptr;
+        int device = 0;
+        for (int i = 3; i + 1 < argc; i += 2) {
+            if (std::strcmp(argv[i], "--out") == 0) out = argv[i + 1];
+            else if (std::strcmp(argv[i], "--params") == 0) params = argv[i + 1];
+            else if (std::strcmp(argv[i], "--device") == 0) device = std::atoi(argv[i + 1]);
+            else {
+                std::fprintf(stderr, "unknown option %s\n", argv[i]);
+                return 2;
+            }
+        }
+        return replay_records(dir, out, params, device);
+    }
     const int N = argc > 1 ? std::atoi(argv[1]) : 256;
     const int frames = argc > 2 ? std::atoi(argv[2]) : 300;
     const uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 0;

@@ -112,3 +112,22 @@ class Scenario:
         for _ in range(count):
             self.advance()
             yield self.measure()
+
+
+def translated_sequence(base, frames, dx=-1.4, dy=-0.45):
+    """Image sequence of a fronto-parallel textured plane under lateral camera motion: frame i is the 8-bit image `base`
+    translated by i * (dx, dy) pixels (bilinear, wrap-around).  Used by the full-loop benchmark and the replay tests
+    (the reference ships single test images, no sequence)."""
+    base = np.asarray(base).astype(np.float32)
+    out = []
+    for i in range(frames):
+        sx, sy = i * dx, i * dy
+        ix, iy = int(np.floor(sx)), int(np.floor(sy))
+        fx, fy = sx - ix, sy - iy
+        a = np.roll(base, (iy, ix), axis=(0, 1))
+        b = np.roll(base, (iy, ix + 1), axis=(0, 1))
+        c = np.roll(base, (iy + 1, ix), axis=(0, 1))
+        d = np.roll(base, (iy + 1, ix + 1), axis=(0, 1))
+        img = (1 - fy) * ((1 - fx) * a + fx * b) + fy * ((1 - fx) * c + fx * d)
+        out.append(np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8)))
+    return out

@@ -499,3 +499,33 @@ def test_launch_fusion_knobs_do_not_change_bits(monkeypatch):
                     ref = st
                 for key in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"):
                     assert np.array_equal(st[key], ref[key]), (fg, fl, key)
+
+
+@pytest.mark.parametrize("m,npos,shuffle", [(130, 70, False), (130, 70, True), (512, 300, True), (1100, 600, True)])
+def test_indefinite_matrix_goes_through_the_signed_factorisation(m, npos, shuffle):
+    """The reference's SimplicialLDLT carries negative pivots along (TightlyCoupledEKF.cpp:577-580); so does the sweep:
+    a diagonal tile that meets a non-positive pivot is factored again as U S U^T and the signs ride through the trailing
+    updates and into the gain.  Quasi-definite test matrix [[A, B], [B^T, -C]] (A, C positive definite: LDL^T exists for
+    every symmetric permutation, with npos positive and m - npos negative pivots), optionally permuted so that the
+    signs are mixed inside every 64-block; 1100 rows exercise the split sweep."""
+    g = TightlyCoupledEKF(max_features=4)
+    rng = np.random.default_rng(m + npos)
+    def spd(k):
+        Q = rng.standard_normal((k, k))
+        return Q @ Q.T / k + np.eye(k) * 0.2
+    S = np.zeros((m, m))
+    S[:npos, :npos] = spd(npos)
+    S[npos:, npos:] = -spd(m - npos)
+    B = 0.1 * rng.standard_normal((npos, m - npos))
+    S[:npos, npos:] = B
+    S[npos:, :npos] = B.T
+    if shuffle:
+        perm = rng.permutation(m)
+        S = S[np.ix_(perm, perm)]
+    S = S.astype(np.float32)
+    Cr = rng.standard_normal((90, m)).astype(np.float32)
+    _, X, info = g.test_cholesky_solve(S, Cr)
+    assert info == 1  # the pivot flag is a warning: S is not positive definite
+    ref = Cr.astype(np.float64) @ np.linalg.inv(S.astype(np.float64))
+    assert relf(X, ref) < 5e-5 * max(1.0, np.linalg.cond(S.astype(np.float64)) / 50.0), relf(X, ref)
+    g.close()
