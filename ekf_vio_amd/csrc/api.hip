@@ -154,6 +154,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->sweep_mode = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_SCHUR");  // tuning knob: 1 = Sigma (I - K H)^T and K as Schur tiles inside the sweep instead of two GEMMs behind it
+        if (e) f->schur = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches
         if (e) f->fuse_linearize = atoi(e) ? 1 : 0;
     }
@@ -601,7 +603,7 @@ int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_laun
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     HIPC(f, hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
-    launch_update_gemms_scratch(f, f->last_m, reps);
+    const int per_rep = launch_update_gemms_scratch(f, f->last_m, reps);
     hipError_t ce = hipStreamEndCapture(f->stream, &g);
     if (ce != hipSuccess || !g) {
         f->last_error = std::string("graph capture: ") + hipGetErrorString(ce);
@@ -620,7 +622,7 @@ int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_laun
     // P2 is the predict's scratch and must stay zero outside the live block
     HIPC(f, hipMemsetAsync(f->P2, 0, sizeof(float) * (size_t)f->ldp * f->ldp, f->stream));
     HIPC(f, hipStreamSynchronize(f->stream));
-    *avg_launch_us = 1e3 * ms / (2.0 * reps);
+    *avg_launch_us = 1e3 * ms / ((double)per_rep * reps);
     const int m_pad = round_up(f->last_m, 64);
     if (flops_per_launch) *flops_per_launch = 2.0 * f->n * (double)f->n * m_pad;
     return EKFVIO_OK;

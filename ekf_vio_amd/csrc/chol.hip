@@ -612,16 +612,32 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
 // latency-optimal form for few tiles).  SOLVE = false: the panel blocks L_ik were written by chol_panel_kernel(k)
 // before (two launches per block step): with thousands of tiles per step (N = 1024: mb = 32) the per-tile panel
 // solves are 60 % redundant work.
+//
+// Schur tiles (SchurArgs, SOLVE = true only).  Eliminating A from the symmetric matrix [[A, X^T, I], [X, Sigma, 0], [I, 0, 0]]
+// leaves Sigma - X A^-1 X^T in the (X, X) block and -X A^-1 = -K in the (X, I) block: both are just more trailing
+// tiles of this same sweep,
+//     T2(a,b) -= Y_ak S_k Y_bk^T           nb(nb+1)/2 tiles (a >= b), the mirror image written from the same product,
+//     K(a,c)  += Y_ak S_k Z_ck^T, c <= k   nb*(k+1) tiles (block (I_c, k) is zero before step c),
+// with Y_ak = X_ak U_kk^-T and Z_ck = I_ck U_kk^-T formed by the tile itself like every other panel block.  They fill
+// compute units the latency-bound chain leaves idle, and the gain GEMM and the first Joseph GEMM (20 us behind the
+// sweep at N = 256) disappear; the last block step is then a launch of Schur tiles only.
+// Which Joseph factor this is: X = Sigma H^T, so X A^-1 X^T = Sigma H^T K^T and T2 = Sigma (I - K H)^T -- the RIGHT factor
+// applied, where the reference forms the left one first, (I - K H) Sigma (:594).  Sigma is symmetric only to rounding, so
+// the two are not transposes of each other, and finishing T2 as if it were the left factor ((.)(I - K H)^T once more)
+// never damps the rows of Sigma's antisymmetric part: the filter drifts apart within ~100 steps (measured).  The caller
+// therefore applies the LEFT factor to T2: Sigma' = (I - K H) T2 + K R K^T = T2 + K (R K^T - H T2) (launch_update), which
+// is the reference's (I - K H) Sigma (I - K H)^T + K R K^T term for term.
+struct SchurArgs {
+    float* P = nullptr;   // Sigma in, T out (in place), nb x nb tiles of 64, column-major, ldp
+    int ldp = 0;
+    float* K = nullptr;   // n_pad x m_pad, column-major, ldk; written, never read (first touch of a tile stores)
+    int ldk = 0;
+    int nb = 0;           // X row blocks = n_pad / 64
+};
 template <bool SOLVE>
 __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
                                                         float* __restrict__ Linv, int k, int mb, int idb0, int* info,
-                                                        unsigned long long* Lsign, long long* dbg) {
-    // diagnostic phase stamps of the chain workgroup (scripts/chol_step_stamps.py); dbg is null in production
-#define CSTAMP(slot)                                                                                         \
-    do {                                                                                                     \
-        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[32 + 8 * k + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-    CSTAMP(0);
+                                                        unsigned long long* Lsign, long long* dbg, SchurArgs sc) {
     __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];   // A_ik, then L_ik
     __shared__ __attribute__((aligned(16))) float Tj[PB * PLD];   // A_jk, then L_jk
     // L_kk, later the updated next diagonal tile.  Without the in-kernel panel solves (SOLVE = false) only the chain
@@ -633,18 +649,51 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
     const int rr = mb - 1 - k, ntri = rr * (rr + 1) / 2;
-    int t = blockIdx.x, i, j;
+    const int rb = idb0;  // extra row blocks: idb0 - mb of X, then mb of I
+    // Tile 0 is the chain (next diagonal tile: latency-bound, wants a compute unit of its own).  Workgroups beyond the
+    // 256th double up on the compute units of the first ones, so in a larger grid the chain trades places with workgroup
+    // 255, whose compute unit is the last to receive a second resident.
+    int t = blockIdx.x;
+    if (SOLVE && rr > 0 && gridDim.x > 256) {
+        if (t == 0) t = 255;
+        else if (t == 255) t = 0;
+    }
+    const bool chain = rr > 0 && t == 0;
+    // diagnostic phase stamps of the chain workgroup (scripts/chol_step_stamps.py); dbg is null in production
+#define CSTAMP(slot)                                                                                         \
+    do {                                                                                                     \
+        if (dbg && chain && threadIdx.x == 0) dbg[32 + 8 * k + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    CSTAMP(0);
+    int i, j;
+    int kind = 0;  // 0: tile of the augmented matrix, 1: T tile, 2: K tile
     if (t < ntri) {
         // lower-triangular tile index: t = ii(ii+1)/2 + jj, 0 <= jj <= ii
         int ii = 0;
         while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
         i = k + 1 + ii;
         j = k + 1 + (t - ii * (ii + 1) / 2);
-    } else {
+    } else if (t < ntri + rb * rr) {
         t -= ntri;
         i = mb + t / rr;
         j = k + 1 + t % rr;
         if (i >= idb0 && i - idb0 > k) return;  // identity block row: block (i,k) is still zero
+    } else {
+        // Schur tiles: both operands are panel blocks of extra row blocks
+        int u = t - ntri - rb * rr;
+        const int nT = sc.nb * (sc.nb + 1) / 2;
+        if (u < nT) {
+            int aa = 0;
+            while ((aa + 1) * (aa + 2) / 2 <= u) aa++;
+            i = mb + aa;
+            j = mb + (u - aa * (aa + 1) / 2);
+            kind = 1;
+        } else {
+            u -= nT;
+            i = mb + u % sc.nb;
+            j = idb0 + u / sc.nb;  // identity row block c = u / nb <= k
+            kind = 2;
+        }
     }
 
     // negative pivots of block column k (zero unless diagonal tile k went through the U S U^T path): a scalar load
@@ -659,10 +708,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         if (i != j)
             tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
         else
-            tri_solve_fwd(Ti, Tl, Tinv, wave, lane, (dbg && blockIdx.x == 0) ? dbg + 960 + 4 * k : nullptr);
+            tri_solve_fwd(Ti, Tl, Tinv, wave, lane, (dbg && chain) ? dbg + 960 + 4 * k : nullptr);
         __syncthreads();
         CSTAMP(2);
-        if (j == k + 1) {
+        // the panel blocks of the extra rows are results of their own only without Schur tiles (the gain GEMM reads them)
+        if (kind == 0 && j == k + 1 && (i < mb || sc.P == nullptr)) {
             float* dst = L + (size_t)k * PB * ldl + (size_t)i * PB;
             if (neg != 0ull && i >= idb0) store_tile_signed(Ti, dst, ldl, tid, neg);  // identity rows carry S into the gain
             else store_tile(Ti, dst, ldl, tid);
@@ -674,9 +724,20 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
     // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
     const float* Bj = (i != j) ? Tj : Ti;
-    float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
+    // where the tile's target lives: the augmented matrix itself, Sigma (T tiles) or the gain (K tiles)
+    float* Sij;
+    int ldt;
+    if (kind == 0) {
+        Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
+        ldt = lds;
+    } else if (kind == 1) {
+        Sij = sc.P + (size_t)(j - mb) * PB * sc.ldp + (size_t)(i - mb) * PB;
+        ldt = sc.ldp;
+    } else {
+        Sij = sc.K + (size_t)(j - idb0) * PB * sc.ldk + (size_t)(i - mb) * PB;
+        ldt = sc.ldk;
+    }
     const int r = wr * 32 + (lane & 31);
-    const bool chain = (i == k + 1 && j == k + 1);
 #ifndef EKF_CHOL_LATE_TARGET
     // The chain workgroup requests its target tile BEFORE the 64^3 product and waits for it AFTER: the memory round
     // trip runs under the MFMA stream.  The compiler cannot express that (it waits for a load before the first use it
@@ -736,19 +797,51 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
             if (bad) atomicOr(info, 1);
         }
         CSTAMP(5);
-    } else {
-        // read all sixteen targets, then write them: written as sixteen `-=` the compiler cannot rule out that a store
-        // aliases the next load (the stride lds is a run-time value) and serialises sixteen memory round trips
-        float t[16];
+    } else if (kind == 2) {
+        // K(a,c) = sum_k Y_ak S_k Z_ck^T: the first step that reaches identity block row c stores, later ones add
+        const bool first = (j - idb0) == k;
+        float tv[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            t[q] = Sij[(size_t)c * lds + r];
+            tv[q] = first ? 0.f : Sij[(size_t)c * ldt + r];
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            Sij[(size_t)c * lds + r] = t[q] - up[q];
+            Sij[(size_t)c * ldt + r] = tv[q] + up[q];
+        }
+    } else {
+        // read all sixteen targets, then write them: written as sixteen `-=` the compiler cannot rule out that a store
+        // aliases the next load (the stride is a run-time value) and serialises sixteen memory round trips
+        float tv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            tv[q] = Sij[(size_t)c * ldt + r];
+        }
+        float tm[16];
+        if (kind == 1 && i != j) {
+            // the mirror image T(b,a) -= (Y_ak S Y_bk^T)^T from the same product: transposed through LDS (L_kk's tile is
+            // free: every wavefront is past its substitution), then read back with the lanes along the mirror tile's rows
+            float* Mji = sc.P + (size_t)(i - mb) * PB * sc.ldp + (size_t)(j - mb) * PB;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                tm[q] = Mji[(size_t)c * ldt + r];
+                Tl[r * PLD + c] = up[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                Mji[(size_t)c * ldt + r] = tm[q] - Tl[c * PLD + r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            Sij[(size_t)c * ldt + r] = tv[q] - up[q];
         }
     }
 }
@@ -1063,7 +1156,7 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
 }
 
 #define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
-void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
+void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, bool with_wt) {
     if (!f->gather_attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   EKF_GATHER_POTRF_LDS);
@@ -1071,13 +1164,15 @@ void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_o
     }
     GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
     if (m_on_device) ga.m_dev = f->info + 2;
-    const int nb2 = (m_pad / 64) * (f->ldp / 64);  // 64x64 transposing tiles of Wt
+    const int nb2 = with_wt ? (m_pad / 64) * (f->ldp / 64) : 0;  // 64x64 transposing tiles of Wt (only the first Joseph GEMM reads it)
     hipLaunchKernelGGL(gather_potrf_kernel, dim3(1 + ga.nb1 + nb2), dim3(256), EKF_GATHER_POTRF_LDS, f->stream, ga, f->Laug, f->ld_aug,
                        f->Linv, f->info, f->Lsign, f->sweep_dbg);
 }
 
-void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done) {
-    ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad);
+void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done,
+                       bool schur) {
+    ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad +
+                                 (schur ? (double)n_pad * n_pad * m_pad + (double)n_pad * m_pad * m_pad : 0.0));
     const int mb = m_pad / PB;
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
     const int idb0 = mb + n_pad / PB;
@@ -1096,6 +1191,23 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     // many tiles per step: panel blocks once per step in a launch of their own instead of twice per tile
     const bool split = mb >= EKF_SWEEP_SPLIT_MB;
+    SchurArgs sc;
+    if (schur && !split) {
+        // T and K as Schur tiles of the sweep itself (chol_step_kernel): Sigma is updated in place, the gain lands in Km
+        sc.P = f->P;
+        sc.ldp = f->ldp;
+        sc.K = f->Km;
+        sc.ldk = f->ldp;
+        sc.nb = n_pad / PB;
+        const int nT = sc.nb * (sc.nb + 1) / 2;
+        for (int k = 0; k < mb; k++) {
+            const int r = mb - 1 - k;
+            const dim3 grid(r * (r + 1) / 2 + rb * r + nT + sc.nb * (k + 1));
+            hipLaunchKernelGGL(chol_step_kernel<true>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
+                               f->Lsign, f->sweep_dbg, sc);
+        }
+        return;
+    }
     for (int k = 0; k + 1 < mb; k++) {
         const int r = mb - 1 - k;
         const dim3 grid(r * (r + 1) / 2 + rb * r);
@@ -1103,10 +1215,10 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
             hipLaunchKernelGGL(chol_panel_kernel, dim3(r + rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, r, idb0,
                                f->Lsign, 0);
             hipLaunchKernelGGL(chol_step_kernel<false>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
-                               f->Lsign, f->sweep_dbg);
+                               f->Lsign, f->sweep_dbg, sc);
         } else {
             hipLaunchKernelGGL(chol_step_kernel<true>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
-                               f->Lsign, f->sweep_dbg);
+                               f->Lsign, f->sweep_dbg, sc);
         }
     }
     hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0, f->Lsign,
@@ -1116,11 +1228,79 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
                            f->Lsign);
 }
 
+// Behind the Schur sweep: the gain gets the reference's sparseView prune (:580), G' = K R^T - (H T2)^T, i.e.
+// G'(i,q) = (K R^T)(i,q) - T2(idx[q], i) (the factor of the second Joseph term, Sigma' = T2 + K G'^T, see launch_update),
+// and K y.  One workgroup per 64 x 64 tile of K.  The rows idx[q] of T2 are read with the lanes along q (consecutive
+// measurement rows are 1-2 floats apart in a column of T2: coalesced) and turned through LDS; everything else has the
+// lanes along the state index.  K y is summed per tile (four column phases, then the phases in order) into
+// Kyp[column block][state index]; the second Joseph GEMM's first workgroup adds the column blocks in order: one fixed
+// summation order, same bits every run.
+__global__ __launch_bounds__(256) void joseph_g_kernel(float* __restrict__ K, int ldk, const float* __restrict__ T, int ldp,
+                                                       const int* __restrict__ idx, const float* __restrict__ Rm,
+                                                       const float* __restrict__ zrow, const float* __restrict__ mu, int m,
+                                                       const int* __restrict__ m_dev, float* __restrict__ G, int ldg,
+                                                       float* __restrict__ Kyp) {
+    __shared__ float s_t[64 * 65];
+    __shared__ float s_part[4][64];
+    if (m_dev) m = *m_dev;
+    const int rl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int i = i0 + rl;
+    // the gain's loads go first (they do not depend on anything)
+    float kq[16], kp[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int q = c0 + ph + 4 * u;
+        kq[u] = K[(size_t)q * ldk + i];
+        kp[u] = K[(size_t)(q ^ 1) * ldk + i];
+    }
+    {   // T2(idx[q], i0 + ii): lanes along q
+        const int q = c0 + rl;
+        const int sq = (q < m) ? idx[q] : 0;
+        float tv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) tv[u] = T[(size_t)(i0 + ph + 4 * u) * ldp + sq];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s_t[(ph + 4 * u) * 65 + rl] = tv[u];
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int q = c0 + ph + 4 * u;
+        const float a = (fabsf(kq[u]) > EKF_FLUSH_THRESH) ? kq[u] : 0.f;   // .sparseView(SPARSE_THRESH, SPARSE_EPS)
+        const float b = (fabsf(kp[u]) > EKF_FLUSH_THRESH) ? kp[u] : 0.f;   // the partner column, pruned the same way
+        K[(size_t)q * ldk + i] = a;
+        float g = 0.f;
+        if (q < m) {
+            // (K R^T)(i,q) = K(i,q) R(q,q) + K(i,q^1) R(q,q^1)
+            const float x = a * Rm[2 * q], y = b * Rm[2 * (q ^ 1) + 1];
+            const float kr = ((q ^ 1) < q) ? (y + x) : (x + y);            // ascending measurement index
+            g = kr - s_t[rl * 65 + ph + 4 * u];
+            acc = acc + a * (zrow[q] - mu[idx[q]]);                         // K (z - H mu), :554-555, :600
+        }
+        G[(size_t)q * ldg + i] = g;
+    }
+    s_part[ph][rl] = acc;
+    __syncthreads();
+    if (ph == 0) Kyp[(size_t)blockIdx.y * ldg + i] = ((s_part[0][rl] + s_part[1][rl]) + s_part[2][rl]) + s_part[3][rl];
+}
+
+void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
+    ProfScope ps(f, PC_SOLVE, 3.0 * n_pad * (double)m_pad);
+    hipLaunchKernelGGL(joseph_g_kernel, dim3(n_pad / 64, m_pad / 64), dim3(256), 0, f->stream, f->Km, f->ldp, f->P, f->ldp, f->idx,
+                       f->Rm, f->yres, f->mu, m, m_on_device ? f->info + 2 : nullptr, f->Gm, f->ldp, f->Wt);
+}
+
 // K = X A^-1 = Y L^-1 with Y = X L^-T and L^-T (both from the sweep): one MFMA GEMM that
 // skips the structurally zero part of the triangular operand and prunes like sparseView
 // (:580).  refine != 0 adds one step of residual refinement against L itself,
 // K <- K + (Y - K L) L^-1 (two more GEMMs); on the filter's matrices it changes nothing
 // measurable (the error is dominated by the fp32 factor itself), so it is off by default.
+bool sweep_supports_schur(const ekfvio_filter* f, int m_pad) {
+    return f->schur && f->sweep_mode == 0 && m_pad / PB < EKF_SWEEP_SPLIT_MB;
+}
+
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
                             float* scratch, int ldk, int refine) {
     ProfScope ps(f, PC_SOLVE, (refine ? 3.0 : 1.0) * n * (double)m_pad * m_pad);

@@ -100,6 +100,8 @@ struct ekfvio_filter {
     int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
+    int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.
+                               // Measured equal in step time at N = 256, so the simpler flow is the default.
     int fuse_linearize = 1;    // 1: structured process(dt) is one launch, the Jacobian blocks are formed inside it (EKFVIO_FUSE_LINEARIZE)
     int num_cus = 0;
     int last_m = 0;            // measurement rows of the most recent update (shape of its GEMMs)
@@ -184,6 +186,8 @@ struct GemmEpi {
     int ldg = 0;
     float* mu = nullptr;
     float* Pcol = nullptr;  // column n of P
+    const float* Kyp = nullptr;  // non-null: K y as `kyp_blocks` partial sums (rows of ld kyp_ld), added in order, instead of Pcol
+    int kyp_blocks = 0, kyp_ld = 0;
     int n = 0;
     int* frame_counter = nullptr;
     int frames = 0;
@@ -236,12 +240,17 @@ void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale);
 int add_features_device(ekfvio_filter* f, int k);
 // The two P-update GEMM launches of an update with m measurement rows, `reps` times, into scratch (P2, Gm): the
 // filter state is not touched.  For timing the kernel under its production shape (ekfvio_profile_update_gemms).
-void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);
+int launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);  // returns the GEMM launches per repetition (1 with the Schur sweep, else 2)
 // Augmented blocked Cholesky sweep (chol.hip): Saug = [A; X; I] (row blocks of 64; A is
 // m_pad x m_pad, X has n_pad rows) -> Laug = [L; X L^-T; L^-T], both ld x m_pad column-major.
+// schur: T = Sigma - X A^-1 X^T (in place in f->P) and K = X A^-1 (f->Km) come out of the sweep itself as Schur tiles
+// (chol.hip); not in the split sweep (m_pad >= 64 * EKF_SWEEP_SPLIT_MB) nor the persistent one
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld,
-                       bool first_tile_done = false);
-void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false);
+                       bool first_tile_done = false, bool schur = false);
+bool sweep_supports_schur(const ekfvio_filter* f, int m_pad);
+// K pruned, G = K R - T[:, idx], K y partial sums (one row of f->Wt per 64 measurement columns)
+void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
+void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false, bool with_wt = true);
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);
 // K = X A^-1 (n rows, ldk) from the sweep output: K = Y L^-1 (+ optional residual refinement).
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,

@@ -922,10 +922,12 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     // The gather and the first diagonal tile's factorisation share a launch while that launch is a single round of
     // workgroups at one per compute unit (chol.hip: gather_potrf_kernel); beyond that (N = 1024: thousands of gather
     // workgroups) the gather wants several workgroups per compute unit and the two stay separate.
+    // T = Sigma - X A^-1 X^T and K = X A^-1 as Schur tiles of the sweep (no gain GEMM, no first Joseph GEMM, no (H Sigma)^T)
+    const bool schur = m > 0 && sweep_supports_schur(f, m_pad);
     bool fused_gather = false;
     if (m > 0 && f->sweep_mode == 0 && f->fuse_gather) {
         const int gx = (std::max(ld, m_pad) + 255) / 256;
-        fused_gather = 1 + gx * ((m_pad + GC * GCI - 1) / (GC * GCI)) + (m_pad / 64) * (ld / 64) <= f->num_cus;
+        fused_gather = 1 + gx * ((m_pad + GC * GCI - 1) / (GC * GCI)) + (schur ? 0 : (m_pad / 64) * (ld / 64)) <= f->num_cus;
     }
     {
         ProfScope ps(f, PC_GATHER);
@@ -937,11 +939,11 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         if (m > 0) {
             if (fused_gather) {
                 // the gather and the factorisation of the first diagonal tile share one launch (chol.hip)
-                launch_gather_potrf(f, m, m_pad, n_pad, m_on_device);
+                launch_gather_potrf(f, m, m_pad, n_pad, m_on_device, !schur);
             } else {
                 GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
                 if (m_on_device) ga.m_dev = f->info + 2;
-                const int nb2 = (m_pad / 64) * (ld / 64);  // 64x64 transposing tiles of Wt
+                const int nb2 = schur ? 0 : (m_pad / 64) * (ld / 64);  // 64x64 transposing tiles of Wt
                 hipLaunchKernelGGL(gather_kernel, dim3(ga.nb1 + nb2), dim3(256), 0, f->stream, ga);
             }
         }
@@ -953,7 +955,21 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     e2.n = n;
     e2.frame_counter = d_frame_counter;
     e2.frames = frames;
-    if (m > 0) {
+    if (schur) {
+        // [A; Sigma H^T; I] swept with Sigma and the gain as Schur tiles (chol.hip): K = X A^-1 (:577-580) and, in place,
+        // T2 = Sigma - X A^-1 X^T = Sigma (I - K H)^T, the RIGHT Joseph factor applied (X = Sigma H^T; Sigma is symmetric only
+        // to rounding, so this is not the transpose of the reference's (I - K H) Sigma).  Then K pruned,
+        // G' = K R^T - (H T2)^T and K y; then the left factor: Sigma' = (I - K H) T2 + K R K^T = T2 + K G'^T, which is the
+        // reference's (I - K H) Sigma (I - K H)^T + K R K^T (:594-596), pruned (:625).  Its first workgroup finishes the
+        // mean (:600-609).
+        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather, true);
+        launch_joseph_g(f, m, m_pad, n_pad, m_on_device);
+        ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad, 1);
+        e2.Kyp = f->Wt;
+        e2.kyp_blocks = m_pad / 64;
+        e2.kyp_ld = ld;
+        launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
+    } else if (m > 0) {
         // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
         launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather);
         launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
@@ -979,10 +995,17 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     }
 }
 
-void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
+int launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
     const int n = f->n, ld = f->ldp;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     GemmEpi e1, e2;
+    if (sweep_supports_schur(f, m_pad)) {
+        // with the Schur sweep the update has ONE P-update GEMM: Sigma' = T2 + K G'^T
+        e2.mode = 2;
+        for (int r = 0; r < reps; r++)
+            launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, f->P, ld, f->P2, ld, 1, 0, &e2);
+        return 1;
+    }
     e1.mode = 1;
     e1.inv_idx = f->inv_idx;
     e1.Rm = f->Rm;
@@ -993,6 +1016,7 @@ void launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
         launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P2, ld, 0, 0, &e1);
         launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P2, ld, f->P2, ld, 1, 0, &e2);
     }
+    return 2;
 }
 
 void launch_check_sigma(ekfvio_filter* f, float* d_out) {

@@ -303,10 +303,17 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
         // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256 * GROUPS) {
-            const float v = epi.mu[e] + epi.Pcol[e];
+            float v;
+            if (epi.Kyp) {  // K y arrives as per-column-block partial sums (joseph_g_kernel): added in block order
+                float ky = epi.Kyp[e];
+                for (int cb = 1; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
+                v = epi.mu[e] + ky;
+            } else {
+                v = epi.mu[e] + epi.Pcol[e];
+                epi.Pcol[e] = 0.f;
+            }
             if (e >= 3 && e <= 6) s_q[e - 3] = v;
             else epi.mu[e] = v;
-            epi.Pcol[e] = 0.f;
         }
         __syncthreads();
         if (threadIdx.x < 4) {
@@ -645,10 +652,17 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
         // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256) {
-            const float v = epi.mu[e] + epi.Pcol[e];
+            float v;
+            if (epi.Kyp) {  // K y arrives as per-column-block partial sums (joseph_g_kernel): added in block order
+                float ky = epi.Kyp[e];
+                for (int cb = 1; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
+                v = epi.mu[e] + ky;
+            } else {
+                v = epi.mu[e] + epi.Pcol[e];
+                epi.Pcol[e] = 0.f;
+            }
             if (e >= 3 && e <= 6) s_q[e - 3] = v;
             else epi.mu[e] = v;
-            epi.Pcol[e] = 0.f;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): s_q written
         __builtin_amdgcn_s_barrier();        // only the epilogue's 256 threads are left (WPS = 2: the others returned)

@@ -209,9 +209,10 @@ int ekfvio_profile_reset(ekfvio_filter* f);
 int ekfvio_profile_count(void);
 const char* ekfvio_profile_name(int32_t cls);
 int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t* launches, double* flops);
-/* Mean launch duration (us) of the two P-update GEMMs (Sigma - K W, T + G K^T) at the shape of the most recent
- * update: `reps` pairs replayed back to back from one hipGraph between two HIP events on the handle's stream;
- * results go to scratch, the state is untouched.  flops_per_launch = 2 n n m_pad (may be NULL). */
+/* Mean launch duration (us) of the P-update GEMM(s) at the shape of the most recent update -- Sigma' = T + G K^T, and,
+ * where the sweep does not produce T itself (EKFVIO_SCHUR=0, m >= 1024), T = Sigma - K W as well -- `reps` repetitions
+ * replayed back to back from one hipGraph between two HIP events on the handle's stream; results go to scratch, the
+ * state is untouched.  flops_per_launch = 2 n n m_pad (may be NULL). */
 int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_launch_us, double* flops_per_launch);
 
 /* Raw kernels for unit tests (column-major, device copies made internally).  variant: 0 = the

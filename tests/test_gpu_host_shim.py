@@ -41,7 +41,7 @@ def test_cpp_replay_of_records_equals_the_python_node(tmp_path):
         name = "frame_%03d.pgm" % i
         with open(tmp_path / name, "wb") as fh:
             fh.write(b"P5\n# replay test\n640 480\n255\n" + im.tobytes())
-        stamp = 100.0 + i / 30.0
+        stamp = float("%.9f" % (100.0 + i / 30.0))  # what the text record holds
         lines.append("image %.9f %s %s" % (stamp, name, " ".join("%.9g" % k for k in K)))
         for j in range(3):  # IMU at a higher rate between the frames
             lines.append("imu %.9f 0.0 0.1 0.0 0.0 0.0 9.81" % (stamp + (j + 1) / 120.0))
@@ -64,7 +64,7 @@ def test_cpp_replay_of_records_equals_the_python_node(tmp_path):
     # the Python mirror of the node on the same records
     v = EKFVIO(max_features=48, replenish=1, fast_threshold=50, inverse_image_scale=1)
     for i, im in enumerate(imgs):
-        stamp = 100.0 + i / 30.0
+        stamp = float("%.9f" % (100.0 + i / 30.0))
         rc = v.addFrame(stamp, im, np.array(K, np.float32))
         od = v.odometry()
         row = np.concatenate([od["position"], od["orientation_wxyz"], od["linear"], od["angular"]]).astype(np.float32)

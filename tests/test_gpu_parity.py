@@ -452,6 +452,7 @@ def test_persistent_sweep_matches_per_step_sweep(monkeypatch):
     sc = Scenario(N, seed=2)
     fr = list(sc.frames(3))
     res = []
+    monkeypatch.setenv("EKFVIO_SCHUR", "0")  # the persistent sweep has no Schur tiles: compare like with like
     for mode in ("0", "1"):
         monkeypatch.setenv("EKFVIO_SWEEP", mode)
         g = TightlyCoupledEKF(max_features=N)
@@ -529,3 +530,43 @@ def test_indefinite_matrix_goes_through_the_signed_factorisation(m, npos, shuffl
     ref = Cr.astype(np.float64) @ np.linalg.inv(S.astype(np.float64))
     assert relf(X, ref) < 5e-5 * max(1.0, np.linalg.cond(S.astype(np.float64)) / 50.0), relf(X, ref)
     g.close()
+
+
+@pytest.mark.parametrize("N", [20, 100, 256])
+def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
+    """Default (EKFVIO_SCHUR=0): the sweep yields Y and L^-T, K = Y L^-1 and T = (I - K H) Sigma are MFMA GEMMs behind it
+    (the reference's order of operations, :580-594), then Sigma' = T + G K^T.  EKFVIO_SCHUR=1: T2 = Sigma (I - K H)^T and
+    K = X A^-1 come out of the sweep itself as Schur tiles, then Sigma' = (I - K H) T2 + K R K^T.  Same Joseph update term
+    for term, other summation order: both must sit within the fp64 yardstick, and close to each other."""
+    sc = Scenario(N, seed=4)
+    o64 = OracleFilter(np.float64)
+    uv = sc.initial_features()
+    o64.add_new_features(uv)
+    it = sc.frames(8)
+    for _ in range(5):
+        z, R, p = next(it)
+        o64.process(sc.dt), o64.update(z, R, p)
+    st = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in o64.get_state().items()}
+    z, R, p = next(it)
+    p = p.copy()
+    p[3] = 0
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EKFVIO_SCHUR", mode)
+        g = TightlyCoupledEKF(max_features=N)
+        g.set_state(st)
+        g.process(sc.dt)
+        if mode == "1":
+            o64.set_state(g.get_state())
+        assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+        out[mode] = g.get_state()
+        g.close()
+    o32 = OracleFilter(np.float32)
+    o32.set_state(o64.get_state())
+    o32.update(z, R, p), o64.update(z, R, p)
+    s32, s64 = o32.get_state(), o64.get_state()
+    for mode in ("1", "0"):
+        assert maxabs(out[mode]["base_mu"], s64["base_mu"]) <= ACC_FACTOR * maxabs(s32["base_mu"], s64["base_mu"]) + MU_FLOOR, mode
+        assert relf(out[mode]["Sigma"], s64["Sigma"]) <= ACC_FACTOR * relf(s32["Sigma"], s64["Sigma"]) + SIG_FLOOR, mode
+    assert np.array_equal(out["1"]["last_klt"], out["0"]["last_klt"]) and np.array_equal(out["1"]["del_flag"], out["0"]["del_flag"])
+    assert relf(out["1"]["Sigma"], out["0"]["Sigma"]) < 2e-5 and maxabs(out["1"]["base_mu"], out["0"]["base_mu"]) < 2e-5

@@ -76,10 +76,13 @@ def _assert_within_yardstick(E):
     assert E["sig_gpu"] <= ACC_FACTOR * E["sig_o32"] + SIG_FLOOR, E
 
 
-def test_teacher_forced_n256_including_failed_landmarks(oracle_threads):
-    """BASELINE config 2's shape.  The teacher trajectory is the fp64 oracle's (so every step starts from a sane,
+@pytest.mark.parametrize("schur", ["0", "1"])
+def test_teacher_forced_n256_including_failed_landmarks(oracle_threads, monkeypatch, schur):
+    """BASELINE config 2's shape, with the default flow (gain GEMM + first Joseph GEMM behind the sweep) and with the Schur
+    sweep (EKFVIO_SCHUR=1: Sigma (I - K H)^T and K as trailing tiles of the sweep itself, chol.hip).  The teacher trajectory is the fp64 oracle's (so every step starts from a sane,
     converged state: the raw prior's cond(S) ~ 1e7 first update is covered at N <= 100 with its own yardstick)."""
     N = 256
+    monkeypatch.setenv("EKFVIO_SCHUR", schur)
     sc = Scenario(N, seed=0)
     g = TightlyCoupledEKF(max_features=N)
     o32, o64, teacher = OracleFilter(np.float32), OracleFilter(np.float64), OracleFilter(np.float64)
