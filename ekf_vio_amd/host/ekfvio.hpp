@@ -91,6 +91,17 @@ struct Params {
         else throw Error(EKFVIO_EINVAL, "unknown parameter: " + key);
     }
 
+    // every private parameter name the node accepts (EKFVIO.cpp:20-67): what a ROS front end asks the parameter server for
+    static std::vector<std::string> names() {
+        std::vector<std::string> out = {"num_features", "fast_threshold", "fast_blur_sigma", "inverse_image_scale", "kill_pad",
+                                        "min_klt_eigen_val", "min_new_feature_dist", "max_pyramids", "klt_window_size",
+                                        "default_point_depth", "default_point_depth_variance",
+                                        "default_point_homogenous_variance", "frame_buffer_size"};
+        for (const auto& e : Params().node) out.push_back(e.first);
+        for (const auto& e : ignored()) out.push_back(e.first);
+        return out;
+    }
+
     static Params fromMap(const std::map<std::string, std::string>& kv) {
         Params p;
         for (const auto& e : kv) p.set(e.first, e.second);
@@ -233,6 +244,12 @@ class TightlyCoupledEKF {
     std::vector<Vector3f> featureMus() {
         std::vector<Vector3f> out(numFeatures());
         chk(ekfvio_get_features(h_, out.empty() ? nullptr : out[0].data(), nullptr, nullptr));
+        return out;
+    }
+    // Feature::getDeleteFlag per landmark (set when the tracker lost it, TightlyCoupledEKF.cpp:528; read by publishInsight)
+    std::vector<uint8_t> deleteFlags() {
+        std::vector<uint8_t> out(numFeatures());
+        chk(ekfvio_get_features(h_, nullptr, nullptr, out.empty() ? nullptr : out.data()));
         return out;
     }
     int numFeatures() const { return ekfvio_num_features(h_); }

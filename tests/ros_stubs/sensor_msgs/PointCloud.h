@@ -1,0 +1,14 @@
+// stand-in: see tests/ros_stubs/README.md
+#pragma once
+#include <sensor_msgs/Imu.h>
+namespace sensor_msgs {
+struct ChannelFloat32 {
+    std::string name;
+    std::vector<float> values;
+};
+struct PointCloud {
+    std_msgs::Header header;
+    std::vector<geometry_msgs::Point32> points;
+    std::vector<ChannelFloat32> channels;
+};
+}  // namespace sensor_msgs

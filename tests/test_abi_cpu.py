@@ -130,3 +130,22 @@ frame_buffer_size: 2
     for bad in ("num_feature: 10\n", "fast_threshold: many\n", "frame_buffer_size: 3\n", "inverse_image_scale: 2.5\n", "just words\n"):
         rc, err = _print_config(tmp_path, bad)
         assert rc == 2 and "error" in err, (bad, err)
+
+
+def test_ros_node_source_type_checks_against_stub_headers():
+    """the ROS1 front end (ekf_vio_amd/host/ros/ekfvio_node.cpp) cannot be built here (no ROS in the
+    image or on the GPU boxes).  It is type-checked against declaration-only stand-ins for the ROS headers it includes
+    (tests/ros_stubs), so that the node source and the host shim it calls stay in step; without ROS headers on the include
+    path the translation unit is empty and must compile as such."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "ekf_vio_amd", "host", "ros", "ekfvio_node.cpp")
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror"]
+    out = subprocess.run(base + ["-I", os.path.join(root, "tests", "ros_stubs"), src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    out = subprocess.run(base + [src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    text = open(src).read()
+    for needle in ("subscribeCamera", "advertise<nav_msgs::Odometry>", "advertise<sensor_msgs::PointCloud>", "waitForTransform",
+                   "\"intensity\"", "imu_topic", "sendTransform"):
+        assert needle in text, needle
