@@ -19,7 +19,8 @@ class Config(C.Structure):
                 ("kill_pad", C.c_int32), ("max_image_width", C.c_int32), ("max_image_height", C.c_int32),
                 ("use_principal_point", C.c_int32), ("inverse_image_scale", C.c_int32), ("fast_threshold", C.c_int32),
                 ("min_new_feature_dist", C.c_int32), ("fast_blur_sigma", C.c_float), ("replenish", C.c_int32),
-                ("sample_based_uncertainty", C.c_int32)]
+                ("sample_based_uncertainty", C.c_int32), ("use_imu", C.c_int32), ("imu_gyro_variance", C.c_float),
+                ("imu_accel_variance", C.c_float), ("gravity", C.c_float * 3)]
 
 
 class EkfvioError(RuntimeError):
@@ -35,7 +36,7 @@ SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_r
            "ekfvio_get_feature_cov", "ekfvio_get_depth_variance", "ekfvio_set_feature_cov", "ekfvio_metric2pixel_map",
            "ekfvio_pixel2metric_map", "ekfvio_get_odometry", "ekfvio_get_points", "ekfvio_check_sigma", "ekfvio_set_state",
            "ekfvio_klt_push_frame", "ekfvio_klt_track", "ekfvio_klt_track_points", "ekfvio_klt_get_level",
-           "ekfvio_klt_uncertainty_points", "ekfvio_step_image", "ekfvio_replenish", "ekfvio_fast_detect", "ekfvio_test_blurred_level0", "ekfvio_imu",
+           "ekfvio_klt_uncertainty_points", "ekfvio_step_image", "ekfvio_replenish", "ekfvio_fast_detect", "ekfvio_test_blurred_level0", "ekfvio_imu", "ekfvio_imu_update",
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
            "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
            "ekfvio_profile_update_gemms", "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps", "ekfvio_test_sweep_stamps",
@@ -76,7 +77,7 @@ def load(build_if_missing=True):
         "ekfvio_klt_track_points": [vp, fp, fp, i32, fp, u8p],
         "ekfvio_klt_uncertainty_points": [vp, fp, fp, i32, fp],
         "ekfvio_klt_get_level": [vp, i32, ip, ip, u8p, C.POINTER(C.c_int16)],
-        "ekfvio_step_image": [vp, C.c_double, u8p, i32, i32, i32, fp], "ekfvio_imu": [vp, C.c_double, fp, fp],
+        "ekfvio_step_image": [vp, C.c_double, u8p, i32, i32, i32, fp], "ekfvio_imu": [vp, C.c_double, fp, fp], "ekfvio_imu_update": [vp, fp, fp],
         "ekfvio_replenish": [vp, ip, ip], "ekfvio_fast_detect": [vp, i32, i32, i32, ip, ip, ip], "ekfvio_test_blurred_level0": [vp, u8p],
         "ekfvio_upload_measurements": [vp, i32, fp, fp, u8p], "ekfvio_run_uploaded": [vp, i32, i32, f32],
         "ekfvio_synchronize": [vp], "ekfvio_profile_enable": [vp, i32], "ekfvio_profile_reset": [vp],

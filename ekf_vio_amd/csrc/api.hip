@@ -107,6 +107,12 @@ int ekfvio_default_config(ekfvio_config* c) {
     c->fast_blur_sigma = 0.f;     // D_FAST_BLUR_SIGMA (0 = no blur)
     c->replenish = 0;             // 1: ekfvio_step_image runs replenishFeatures (EKFVIO.cpp:154,172) itself
     c->sample_based_uncertainty = 0;  // reference behaviour: estimateUncertainty's constant (KLTTracker.cpp:100-106)
+    c->use_imu = 0;                   // reference behaviour: imu_callback only logs (EKFVIO.cpp:113-115)
+    c->imu_gyro_variance = 1e-4f;
+    c->imu_accel_variance = 1e-2f;
+    c->gravity[0] = 0.f;
+    c->gravity[1] = 9.81f;
+    c->gravity[2] = 0.f;
     return EKFVIO_OK;
 }
 
@@ -440,7 +446,32 @@ int ekfvio_set_state(ekfvio_filter* f, int32_t N, const float* base_mu, const fl
     return EKFVIO_OK;
 }
 
-int ekfvio_imu(ekfvio_filter* f, double, const float*, const float*) { return f ? EKFVIO_OK : EKFVIO_EINVAL; }
+int ekfvio_imu_update(ekfvio_filter* f, const float* gyro, const float* accel) {
+    if (!f || !gyro || !accel) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    launch_imu_update(f, gyro, accel);
+    HIPC(f, hipGetLastError());
+    return EKFVIO_OK;
+}
+
+int ekfvio_imu(ekfvio_filter* f, double stamp, const float* gyro, const float* accel) {
+    if (!f) return EKFVIO_EINVAL;
+    if (!f->cfg.use_imu) return EKFVIO_OK;  // the reference's callback only logs
+    if (!gyro || !accel) return EKFVIO_EINVAL;
+    if (!f->have_stamp) {  // tc_ekf.t is set by the first message (EKFVIO.cpp:148-150 does it for the first frame)
+        f->t_stamp = stamp;
+        f->have_stamp = true;
+        return EKFVIO_OK;
+    }
+    const double dt = stamp - f->t_stamp;
+    if (!(dt >= 0)) return EKFVIO_EINVAL;
+    HIPC(f, hipSetDevice(f->device));
+    launch_predict(f, (float)dt);
+    f->t_stamp = stamp;
+    launch_imu_update(f, gyro, accel);
+    HIPC(f, hipGetLastError());
+    return EKFVIO_OK;
+}
 
 // ---- uploaded measurement sequences ---------------------------------------------------
 int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z, const float* R, const uint8_t* pass) {

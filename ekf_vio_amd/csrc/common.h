@@ -232,6 +232,8 @@ void launch_check_sigma(ekfvio_filter* f, float* d_out);
 int klt_level_pitch(int w);
 int klt_border();
 void klt_intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy);
+// imu.hip
+void launch_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[3]);
 // fast.hip
 int fast_alloc(ekfvio_filter* f);
 void fast_free(ekfvio_filter* f);

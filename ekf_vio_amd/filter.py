@@ -35,7 +35,10 @@ class TightlyCoupledEKF:
         cfg.default_point_depth_variance = default_point_depth_variance
         cfg.default_point_homogenous_variance = default_point_homogenous_variance
         for k, v in cfg_overrides.items():
-            setattr(cfg, k, v)
+            if k == "gravity":
+                cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = (float(x) for x in v)
+            else:
+                setattr(cfg, k, v)
         self.cfg = cfg
         self.h = C.c_void_p()
         rc = self.lib.ekfvio_create(C.byref(cfg), device, C.c_void_p(stream) if stream else None, C.byref(self.h))
@@ -127,6 +130,12 @@ class TightlyCoupledEKF:
         v = C.c_float(0)
         self._chk(self.lib.ekfvio_get_depth_variance(self.h, index, C.byref(v)))
         return float(v.value)
+
+    def imuUpdate(self, gyro, accel):
+        """the IMU measurement update alone (no propagation); asynchronous."""
+        g = np.ascontiguousarray(gyro, dtype=np.float32)
+        a = np.ascontiguousarray(accel, dtype=np.float32)
+        self._chk(self.lib.ekfvio_imu_update(self.h, _fp(g), _fp(a)))
 
     def checkSigma(self):
         a, b = C.c_float(0), C.c_float(0)
@@ -330,7 +339,8 @@ class EKFVIO:
         return xy[:k].copy(), sc[:k].copy()
 
     def imu_callback(self, stamp, gyro, accel):
-        """EKFVIO::imu_callback (EKFVIO.cpp:113-115): a logging stub in the reference."""
+        """EKFVIO::imu_callback (EKFVIO.cpp:113-115): a logging stub in the reference, and a no-op here unless the filter was
+        created with use_imu=1 (then: propagate to `stamp`, IMU measurement update)."""
         g = np.ascontiguousarray(gyro, dtype=np.float32)
         a = np.ascontiguousarray(accel, dtype=np.float32)
         self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_imu(self.tc_ekf.h, float(stamp), _fp(g), _fp(a)))

@@ -84,6 +84,12 @@ struct Params {
         else if (key == "default_point_depth") cfg.default_point_depth = (float)number(key, value);
         else if (key == "default_point_depth_variance") cfg.default_point_depth_variance = (float)number(key, value);
         else if (key == "default_point_homogenous_variance") cfg.default_point_homogenous_variance = (float)number(key, value);
+        else if (key == "imu_update") cfg.use_imu = (value == "true" || value == "1") ? 1 : 0;  // not a reference parameter: SURVEY 8(f) F4
+        else if (key == "imu_gyro_variance") cfg.imu_gyro_variance = (float)number(key, value);
+        else if (key == "imu_accel_variance") cfg.imu_accel_variance = (float)number(key, value);
+        else if (key == "gravity_x") cfg.gravity[0] = (float)number(key, value);
+        else if (key == "gravity_y") cfg.gravity[1] = (float)number(key, value);
+        else if (key == "gravity_z") cfg.gravity[2] = (float)number(key, value);
         else if (key == "frame_buffer_size") {
             if (integer(key, value) != 2) throw Error(EKFVIO_EINVAL, "frame_buffer_size: the device keeps exactly two frames (Params.h:58)");
         } else if (node.count(key)) node[key] = value;
@@ -96,7 +102,8 @@ struct Params {
         std::vector<std::string> out = {"num_features", "fast_threshold", "fast_blur_sigma", "inverse_image_scale", "kill_pad",
                                         "min_klt_eigen_val", "min_new_feature_dist", "max_pyramids", "klt_window_size",
                                         "default_point_depth", "default_point_depth_variance",
-                                        "default_point_homogenous_variance", "frame_buffer_size"};
+                                        "default_point_homogenous_variance", "frame_buffer_size", "imu_update",
+                                        "imu_gyro_variance", "imu_accel_variance", "gravity_x", "gravity_y", "gravity_z"};
         for (const auto& e : Params().node) out.push_back(e.first);
         for (const auto& e : ignored()) out.push_back(e.first);
         return out;

@@ -70,6 +70,12 @@ typedef struct ekfvio_config {
     int32_t replenish;                     /* 1: ekfvio_step_image also runs replenishFeatures */
     int32_t sample_based_uncertainty;      /* 0 (reference behaviour): R = 1e-5 I px^2 (estimateUncertainty, KLTTracker.cpp:100-106);
                                               1: R from estimateUncertaintySampleBased (:111-175, dead code there) */
+    /* IMU measurement update (the reference's imu_callback is a logging stub, EKFVIO.cpp:113-115) */
+    int32_t use_imu;                       /* 0 (reference behaviour): ekfvio_imu does nothing; 1: propagate to the record's stamp, then update */
+    float imu_gyro_variance;               /* (rad/s)^2 per axis, default 1e-4 */
+    float imu_accel_variance;              /* (m/s^2)^2 per axis, default 1e-2 */
+    float gravity[3];                      /* gravity in the filter's world frame (= the first camera frame), default (0, 9.81, 0):
+                                              an optical frame, y down; the accelerometer model is a + b_acc - R(q)^T gravity */
 } ekfvio_config;
 
 /* Fills `cfg` with the reference defaults (Params.h D_* values). */
@@ -185,9 +191,14 @@ int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int3
                        int32_t* count);
 /* Test hook: the blurred level 0 (w*h bytes) the last FAST run saw; cfg.fast_blur_sigma must be non-zero. */
 int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out);
-/* EKFVIO::imu_callback (EKFVIO.cpp:113-115) is a logging stub in the reference; kept so the
- * node shim has somewhere to deliver IMU records.  No arithmetic. */
+/* EKFVIO::imu_callback (EKFVIO.cpp:113-115), a logging stub in the reference: with cfg.use_imu = 0 (default) this does
+ * nothing.  With cfg.use_imu = 1 the record first propagates the filter to its stamp -- process(dt = stamp - t),
+ * the reference's motion model; the first record or frame only sets t -- and then updates with z = [gyro; accel],
+ * h = [omega + b_gyr; a + b_acc - R(q)^T gravity], Joseph form (specification: oracle/ekf_oracle.hpp imu_update).
+ * EKFVIO_EINVAL for a stamp before the filter's time.  Asynchronous. */
 int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float accel[3]);
+/* The update alone (no propagation), whatever cfg.use_imu says: for tests and callers that propagate themselves. */
+int ekfvio_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[3]);
 
 /* ---- device-resident measurement sequences (benchmark / replay) ---------------------- */
 /* Copies `frames` consecutive (z, R, pass) triples for the current landmark count to HBM. */

@@ -527,6 +527,145 @@ struct Filter {
         return last_update_info;
     }
 
+    // ---- SURVEY 8(f) F4, second half: an IMU measurement update.  NOT a restatement of reference code: the reference's
+    // imu_callback is a logging stub (EKFVIO.cpp:113-115) and its imu_update_buffer is never touched (EKFVIO.h:59-64).
+    // This is the specification the HIP path (cfg.use_imu) is tested against, written in the reference's style:
+    //   z = [gyro; accel],  h(x) = [omega + b_gyr ;  a + b_acc - R(q)^T g]      (state indices: q 3-6, omega 10-12,
+    //                                                                           a 13-15, b_acc 16-18, b_gyr 19-21)
+    // with R(q)^T g evaluated like every rotation of the filter (Eigen's q*v formula on the conjugate, q not normalised),
+    // H its analytic Jacobian (identities on omega/b_gyr and a/b_acc, -d(R^T g)/dq on the quaternion), the noise
+    // diag(gyro_var x3, accel_var x3), and the update in the reference's Joseph form (:559-609):
+    //   S = H Sigma H^T + R, K = Sigma H^T S^-1, Sigma = (I-KH) Sigma (I-KH)^T + K R K^T evaluated as T = Sigma - K (H Sigma),
+    //   G = K R - T H^T, Sigma = T + G K^T;  mu += K (z - h);  quaternion renormalised;  prune.
+    static void rt_gravity(const T* q4, const T* g3, T* out3, T* jac12 /* d out / d(w,x,y,z), row-major 3x4, may be null */) {
+        const T w = q4[0];
+        const Vec3<T> c{-q4[1], -q4[2], -q4[3]};  // conjugate's vector part
+        const Vec3<T> v{g3[0], g3[1], g3[2]};
+        Vec3<T> uv = cross(c, v);
+        uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+        const Vec3<T> cu = cross(c, uv);
+        out3[0] = v.x + w * uv.x + cu.x;
+        out3[1] = v.y + w * uv.y + cu.y;
+        out3[2] = v.z + w * uv.z + cu.z;
+        if (!jac12) return;
+        jac12[0] = uv.x;  // d/dw
+        jac12[4] = uv.y;
+        jac12[8] = uv.z;
+        for (int k = 0; k < 3; k++) {
+            const Vec3<T> e{k == 0 ? T(1) : T(0), k == 1 ? T(1) : T(0), k == 2 ? T(1) : T(0)};
+            Vec3<T> ev = cross(e, v);
+            ev = {ev.x + ev.x, ev.y + ev.y, ev.z + ev.z};          // d uv / d c_k
+            const Vec3<T> a = cross(e, uv), b = cross(c, ev);
+            // d out / d c_k = w * ev + e_k x uv + c x ev;  c = -(x,y,z), so d/d(x,y,z)_k is its negative
+            jac12[0 + 1 + k] = -(w * ev.x + a.x + b.x);
+            jac12[4 + 1 + k] = -(w * ev.y + a.y + b.y);
+            jac12[8 + 1 + k] = -(w * ev.z + a.z + b.z);
+        }
+    }
+
+    void imu_update(const T* gyro3, const T* accel3, T gyro_var, T accel_var, const T* gravity3) {
+        const int m = 6;
+        // the 16 state columns H touches
+        static const int cols[16] = {3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21};
+        T Hm[6][16] = {};
+        T rg[3], jac[12];
+        rt_gravity(&base_mu[3], gravity3, rg, jac);
+        for (int r = 0; r < 3; r++) {
+            Hm[r][4 + r] = T(1);       // omega
+            Hm[r][13 + r] = T(1);      // b_gyr
+            Hm[3 + r][7 + r] = T(1);   // a
+            Hm[3 + r][10 + r] = T(1);  // b_acc
+            for (int k = 0; k < 4; k++) Hm[3 + r][k] = -jac[4 * r + k];
+        }
+        T y[6];
+        for (int r = 0; r < 3; r++) {
+            y[r] = gyro3[r] - (base_mu[10 + r] + base_mu[19 + r]);
+            y[3 + r] = accel3[r] - ((base_mu[13 + r] + base_mu[16 + r]) - rg[r]);
+        }
+        const T Rd[6] = {gyro_var, gyro_var, gyro_var, accel_var, accel_var, accel_var};
+        // X = Sigma H^T (n x 6), W = H Sigma (6 x n)
+        std::vector<T> X((size_t)n * m, T(0)), W((size_t)m * n, T(0));
+        for (int r = 0; r < m; r++)
+            for (int c = 0; c < 16; c++) {
+                const T h = Hm[r][c];
+                if (h == T(0)) continue;
+                for (int i = 0; i < n; i++) {
+                    X[(size_t)r * n + i] += S(i, cols[c]) * h;
+                    W[(size_t)i * m + r] += h * S(cols[c], i);
+                }
+            }
+        // S = H X + R, its Cholesky, K = X S^-1
+        T Sm[6][6], L[6][6] = {};
+        for (int r = 0; r < m; r++)
+            for (int s = 0; s < m; s++) {
+                T acc = T(0);
+                for (int c = 0; c < 16; c++) acc += Hm[r][c] * X[(size_t)s * n + cols[c]];
+                Sm[r][s] = acc + (r == s ? Rd[r] : T(0));
+            }
+        for (int j = 0; j < m; j++) {
+            T d = Sm[j][j];
+            for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+            L[j][j] = std::sqrt(d);
+            for (int i = j + 1; i < m; i++) {
+                T v = Sm[i][j];  // lower triangle of S
+                for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+                L[i][j] = v / L[j][j];
+            }
+        }
+        std::vector<T> K((size_t)n * m);
+        for (int i = 0; i < n; i++) {
+            T t[6];
+            for (int r = 0; r < m; r++) {  // t L^T = x  (row vector): forward in r
+                T v = X[(size_t)r * n + i];
+                for (int k = 0; k < r; k++) v -= t[k] * L[r][k];
+                t[r] = v / L[r][r];
+            }
+            for (int r = m - 1; r >= 0; r--) {  // k L = t
+                T v = t[r];
+                for (int k = r + 1; k < m; k++) v -= t[k] * L[k][r];  // t holds the solution from r+1 on
+                t[r] = v / L[r][r];
+            }
+            for (int r = 0; r < m; r++) K[(size_t)r * n + i] = t[r];
+        }
+        // T = Sigma - K W on the 16 columns G needs; G = K R - T H^T
+        std::vector<T> G((size_t)n * m);
+        for (int i = 0; i < n; i++)
+            for (int r = 0; r < m; r++) {
+                T th = T(0);
+                for (int c = 0; c < 16; c++) {
+                    const T h = Hm[r][c];
+                    if (h == T(0)) continue;
+                    T t = S(i, cols[c]);
+                    for (int s = 0; s < m; s++) t -= K[(size_t)s * n + i] * W[(size_t)cols[c] * m + s];
+                    th += t * h;
+                }
+                G[(size_t)r * n + i] = K[(size_t)r * n + i] * Rd[r] - th;
+            }
+        // Sigma' = Sigma - K W + G K^T, pruned
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i < n; i++) {
+                T v = S(i, j);
+                for (int s = 0; s < m; s++) v -= K[(size_t)s * n + i] * W[(size_t)j * m + s];
+                for (int s = 0; s < m; s++) v += G[(size_t)s * n + i] * K[(size_t)s * n + j];
+                Sigma[(size_t)j * n + i] = v;
+            }
+        prune(Sigma);
+        // mu += K y; quaternion renormalised (:600-609)
+        const int N = num_features();
+        std::vector<T> mu(n);
+        for (int i = 0; i < BASE; i++) mu[i] = base_mu[i];
+        for (int i = 0; i < 3 * N; i++) mu[BASE + i] = feat_mu[i];
+        for (int i = 0; i < n; i++) {
+            T acc = T(0);
+            for (int r = 0; r < m; r++) acc += K[(size_t)r * n + i] * y[r];
+            mu[i] += acc;
+        }
+        const T qn = std::sqrt(mu[3] * mu[3] + mu[4] * mu[4] + mu[5] * mu[5] + mu[6] * mu[6]);
+        for (int i = 3; i <= 6; i++) mu[i] /= qn;
+        for (int i = 0; i < BASE; i++) base_mu[i] = mu[i];
+        for (int i = 0; i < 3 * N; i++) feat_mu[i] = mu[BASE + i];
+    }
+
     // TightlyCoupledEKF.cpp:699-714: returns min diagonal and max |S(i,j)-S(j,i)|
     void check_sigma(T* min_diag, T* max_asym) {
         T md = S(0, 0), ma = T(0);

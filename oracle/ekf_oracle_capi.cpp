@@ -69,6 +69,13 @@ using oracle::BASE;
         f->del_flag.assign(delN, delN + N);                                                                \
         f->Sigma.assign(sigma, sigma + (size_t)f->n * f->n);                                               \
     }                                                                                                      \
+    extern "C" void P##_imu_update(void* h, const T* gyro3, const T* accel3, T gyro_var, T accel_var,      \
+                                   const T* gravity3) {                                                    \
+        ((oracle::Filter<T>*)h)->imu_update(gyro3, accel3, gyro_var, accel_var, gravity3);                 \
+    }                                                                                                      \
+    extern "C" void P##_rt_gravity(const T* q4, const T* g3, T* out3, T* jac12) {                          \
+        oracle::Filter<T>::rt_gravity(q4, g3, out3, jac12);                                                \
+    }                                                                                                      \
     extern "C" void P##_check_sigma(void* h, T* min_diag, T* max_asym) {                                   \
         ((oracle::Filter<T>*)h)->check_sigma(min_diag, max_asym);                                          \
     }                                                                                                      \

@@ -58,6 +58,8 @@ def _declare(lib):
         g("get_state").argtypes = [vp, tp, tp, tp, u8p, tp]
         g("set_state").argtypes = [vp, i32, tp, tp, tp, u8p, tp]
         g("check_sigma").argtypes = [vp, tp, tp]
+        g("imu_update").argtypes = [vp, tp, tp, ct, ct, tp]
+        g("rt_gravity").argtypes = [tp, tp, tp, tp]
         g("time_steps").argtypes = [vp, i32, ct, tp, tp, u8p]
         g("time_steps").restype = C.c_double
     i16p, fpp = C.POINTER(C.c_int16), C.POINTER(C.c_float)
@@ -190,6 +192,18 @@ class OracleFilter:
         sig = np.ascontiguousarray(np.asarray(st["Sigma"], dtype=self.dtype).T)  # column-major
         self._f("set_state")(self.h, N, _p(base, self.ct), _p(feat, self.ct), _p(klt, self.ct), _p(dele, C.c_uint8),
                              _p(sig, self.ct))
+
+    def imu_update(self, gyro, accel, gyro_var=1e-4, accel_var=1e-2, gravity=(0.0, 9.81, 0.0)):
+        """the IMU measurement update specified in ekf_oracle.hpp (own design; the reference stubs it)."""
+        g, a, gr = self._arr(gyro), self._arr(accel), self._arr(gravity)
+        self._f("imu_update")(self.h, _p(g, self.ct), _p(a, self.ct), self.ct(gyro_var), self.ct(accel_var), _p(gr, self.ct))
+
+    def rt_gravity(self, q, g):
+        """(R(q)^T g, its 3x4 Jacobian with respect to (w,x,y,z)) as the IMU update evaluates them."""
+        q, g = self._arr(q), self._arr(g)
+        out, jac = np.zeros(3, self.dtype), np.zeros(12, self.dtype)
+        self._f("rt_gravity")(_p(q, self.ct), _p(g, self.ct), _p(out, self.ct), _p(jac, self.ct))
+        return out, jac.reshape(3, 4)
 
     def check_sigma(self):
         a, b = self.ct(0), self.ct(0)
