@@ -374,14 +374,17 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
         constexpr int p = P;
         constexpr int c0 = 16 * p;
         // ---- phase F ----
-        if (FV == 10 && wave == 0) {
+        if (FV >= 10 && wave == 0) {
             // FV 10: the generated stream with the panel's LDS loads and stores inside it.  Lanes of the panel (and
             // the dead lanes above it, harmlessly) write their matrix column, the identity lanes of panels 1-3 the rows
             // of the diagonal block's inverse.
             const unsigned lb = static_cast<unsigned>(reinterpret_cast<size_t>(A + c0 * PLD + lane));
             const bool inv_lane = p >= 1 && lane < 16;
             const unsigned sb = inv_lane ? static_cast<unsigned>(reinterpret_cast<size_t>(Tinv + p * 16 * ILD + lane * ILD)) : lb;
-            potrf_panel16_chain_ls<c0>(lb, sb, inv_lane ? 4u : (unsigned)(PLD * 4), (c0 + (lane & 15)) << 2);
+            // FV 12 / 13: the same panel rescheduled so that no LDS latency sits on the pivot chain (gen_ls3)
+            if constexpr (FV == 12) potrf_panel16_chain_ls3<c0>(lb, sb, inv_lane ? 4u : (unsigned)(PLD * 4), (c0 + (lane & 15)) << 2);
+            else if constexpr (FV == 13) potrf_panel16_chain_ls3w<c0>(lb, sb, inv_lane ? 4u : (unsigned)(PLD * 4), (c0 + (lane & 15)) << 2);
+            else potrf_panel16_chain_ls<c0>(lb, sb, inv_lane ? 4u : (unsigned)(PLD * 4), (c0 + (lane & 15)) << 2);
         } else if (wave == 0) {
             float a[16];
 #pragma unroll
@@ -1151,7 +1154,8 @@ __global__ __launch_bounds__(256) void chol_sweep_kernel(float* __restrict__ S, 
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps) {
     const char* e = getenv("EKFVIO_POTRF_FV");  // diagnostic: which factor-phase variant to time
     const int fv = e ? atoi(e) : EKF_POTRF_FV;
-    auto kern = fv == 0 ? potrf64_stamp_kernel<0> : fv == 10 ? potrf64_stamp_kernel<10> : potrf64_stamp_kernel<8>;
+    auto kern = fv == 0 ? potrf64_stamp_kernel<0> : fv == 10 ? potrf64_stamp_kernel<10> : fv == 12 ? potrf64_stamp_kernel<12>
+              : fv == 13 ? potrf64_stamp_kernel<13> : potrf64_stamp_kernel<8>;
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps);
 }
 

@@ -13,7 +13,8 @@
 #define EKF_TILE 64  // block size of every blocked algorithm (GEMM tile edge, Cholesky nb)
 // prune(SPARSE_THRESH, SPARSE_EPS) keeps |x| > 1e-8f*1e-5f (TightlyCoupledEKF.h:13-14, .cpp:117,580,591,625)
 #ifndef EKF_POTRF_FV
-#define EKF_POTRF_FV 10       // factor-phase variant of potrf64_lds (chol.hip): 10 = generated stream incl. its LDS traffic, 8 = without, 0 = plain
+#define EKF_POTRF_FV 12       // factor-phase variant of potrf64_lds (chol.hip): 12 = generated stream incl. its LDS traffic, LDS latency off the
+                              // pivot chain (gen_ls3); 13 = the same with wider fill slots; 10 = round 1's stream; 8 = without the LDS traffic; 0 = plain
 #endif
 #ifndef EKF_SWEEP_SPLIT_MB
 #define EKF_SWEEP_SPLIT_MB 16  // from this many 64-wide block steps on, the sweep solves each panel block once (chol.hip)

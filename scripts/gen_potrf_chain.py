@@ -115,6 +115,99 @@ def gen_ls():
     return out
 
 
+def gen_ls3(slots=(1, 2, 1)):
+    """gen_ls() rescheduled so that no LDS latency sits on the pivot chain.  Column k's update reaches column k+1 AND
+    column k+2 through SGPRs (two v_readlane + two v_fma); only the columns from k+3 on take theirs from the ds_bpermute
+    copy (one v_fmac_f32_dpp each).  Those fills go, earliest deadline first, into the chain's wait states of LATER columns:
+    a wait state of column c only takes fills of columns <= c-2, whose copy has long landed; the one fill per column that
+    cannot wait that long -- (c-1, c+2), due before column c's own SGPR-path update of a[c+2] -- is issued just before that
+    update, behind a counted s_waitcnt (LDS operations return in order: column c's ds_write and ds_bpermute stay in
+    flight).  Per element the updates are still applied in ascending column order, so the results are bit-identical to
+    the plain formulation.  One copy register per column (d0..d12): a column's fills spread over all later columns.
+    slots: fills placed behind v_max / the first v_readlane / v_rsq (the minimum is the hazard distance 1 / 2 / 1)."""
+    out = []
+    emit = out.append
+    lds_ops = 0            # LDS operations issued so far (in-order return)
+    bperm_seq = {}         # column -> sequence number of its ds_bpermute
+    waited_upto = [0]      # every LDS op with sequence number <= this has been waited for
+    pending = []           # fills (deadline column, k, j), not yet issued
+
+    def wait_for(seq):
+        if waited_upto[0] >= seq:
+            return
+        emit("s_waitcnt lgkmcnt(%d)" % (lds_ops - seq))
+        waited_upto[0] = seq
+
+    for j in range(16):
+        emit("ds_read_b32 %%[a%d], %%[lb] offset:%%[p4]*%d" % (j, j))
+        lds_ops += 1
+
+    def issue(k, j):
+        wait_for(bperm_seq[k])
+        emit("v_fmac_f32_dpp %%[a%d], -%%[d%d], %%[a%d] row_newbcast:%d row_mask:0xf bank_mask:0xf" % (j, k, k, j))
+
+    def fill(n, nmin, col):
+        """up to n fills of columns <= col-2 (earliest deadline first); at least nmin issue slots are taken (s_nop pads)"""
+        took = 0
+        pending.sort()
+        i = 0
+        while took < n and i < len(pending):
+            dl, k, j = pending[i]
+            # per element the fills must stay in ascending k: an older column's fill of the same a[j] is always earlier
+            # in this order (smaller k, same deadline), so skipping only ever skips whole (k > col-2) columns
+            if k <= col - 2:
+                pending.pop(i)
+                issue(k, j)
+                took += 1
+            else:
+                i += 1
+        if took < nmin:
+            emit("s_nop %d" % (nmin - took - 1))
+
+    def flush_due(col):
+        pending.sort()
+        while pending and pending[0][0] <= col:
+            dl, k, j = pending.pop(0)
+            issue(k, j)
+
+    for k in range(16):
+        ak = "%%[a%d]" % k
+        emit("; column %d" % k)
+        if k == 0:
+            wait_for(3)                                        # a0, a1, a2 have landed
+        elif k == 1:
+            wait_for(16)                                       # every column of the panel
+        emit("v_max_f32 %%[t], 0x1e3ce508, %s" % ak)
+        fill(slots[0], 1, k)
+        emit("v_readlane_b32 %%[s], %%[t], %%[c0]+%d" % k)
+        fill(slots[1], 2, k)
+        emit("v_rsq_f32 %[t], %[s]")
+        fill(slots[2], 1, k)
+        emit("v_mul_f32 %s, %s, %%[t]" % (ak, ak))
+        emit("ds_write_b32 %%[sb], %s" % ak)
+        lds_ops += 1
+        if k <= 12:
+            emit("ds_bpermute_b32 %%[d%d], %%[addr], %s" % (k, ak))    # one register per column: its fills spread far
+            lds_ops += 1
+            bperm_seq[k] = lds_ops
+            for j in range(k + 3, 16):
+                pending.append((j - 2, k, j))                  # must precede column j-2's SGPR-path update of a[j]
+        if k <= 14:
+            emit("v_readlane_b32 %%[s], %s, %%[c0]+%d" % (ak, k + 1))
+            if k <= 13:
+                emit("v_readlane_b32 %%[s2], %s, %%[c0]+%d" % (ak, k + 2))
+            else:
+                fill(1, 1, k)
+            emit("v_add_u32 %[sb], %[ss], %[sb]")
+            emit("v_fma_f32 %%[a%d], -%s, %%[s], %%[a%d]" % (k + 1, ak, k + 1))
+            if k <= 13:
+                flush_due(k)                                   # every older update of a[k+2] first: ascending order per element
+                emit("v_fma_f32 %%[a%d], -%s, %%[s2], %%[a%d]" % (k + 2, ak, k + 2))
+    assert not pending, pending
+    emit("s_waitcnt lgkmcnt(0)")                              # the compiler does not see these LDS writes
+    return out
+
+
 def main():
     w = sys.stdout.write
     if len(sys.argv) > 1 and sys.argv[1] == "--experiments":  # timing-only variants (wrong results)
@@ -153,7 +246,22 @@ def main():
     w('          [d0] "=&v"(d0), [d1] "=&v"(d1), [t] "=&v"(t), [s] "=&s"(s), [sb] "+v"(sb)\n')
     w('        : [addr] "v"(diag_lane4), [c0] "n"(C0), [lb] "v"(lb), [ss] "v"(ss), [p4] "n"(4 * PLD)\n')
     w('        : "memory");\n')
-    w("}\n")
+    w("}\n\n")
+    w("// gen_ls3(): the same panel with the LDS latency off the pivot chain (two SGPR-path columns, counted waits);\n")
+    w("// _ls3w: the same with wider fill slots behind the chain's links.\n")
+    for name, slots in (("ls3", (1, 2, 1)), ("ls3w", (2, 3, 2))):
+        w("template <int C0>\n")
+        w("__device__ __forceinline__ void potrf_panel16_chain_%s(unsigned lb, unsigned sb, unsigned ss, int diag_lane4) {\n" % name)
+        w("    float " + ", ".join("a%d" % i for i in range(16)) + ", " + ", ".join("d%d" % i for i in range(13)) + ", t, s, s2;\n")
+        w("    asm volatile(\n")
+        for ln in gen_ls3(slots):
+            w('        "%s\\n\\t"\n' % ln)
+        w("        : " + ", ".join('[a%d] "=&v"(a%d)' % (i, i) for i in range(16)) + ",\n")
+        w("          " + ", ".join('[d%d] "=&v"(d%d)' % (i, i) for i in range(13)) + ",\n")
+        w('          [t] "=&v"(t), [s] "=&s"(s), [s2] "=&s"(s2), [sb] "+v"(sb)\n')
+        w('        : [addr] "v"(diag_lane4), [c0] "n"(C0), [lb] "v"(lb), [ss] "v"(ss), [p4] "n"(4 * PLD)\n')
+        w('        : "memory");\n')
+        w("}\n\n")
 
 
 if __name__ == "__main__":

@@ -110,17 +110,17 @@ def test_cholesky_flags_non_positive_pivot():
 def test_generated_pivot_chain_matches_plain_formulation_bits(monkeypatch):
     """potrf64_lds's production factor phase is a generated, hand-scheduled instruction stream
     (csrc/potrf_chain.inc, scripts/gen_potrf_chain.py).  The diagnostic entry factors the same SPD 64x64 block with
-    it (variants 8 and 10) and with the plain readlane + fma formulation (variant 0): L and the 16x16 inverses must agree
+    it (variants 8, 10, 12, 13) and with the plain readlane + fma formulation (variant 0): L and the 16x16 inverses must agree
     bit for bit (stamps[12], [13] are FNV-1a hashes of their bits)."""
     import ctypes as C
     g = TightlyCoupledEKF(max_features=4)
     hashes = []
-    for fv in ("0", "8", "10"):  # plain, generated chain, generated chain with its LDS loads/stores (production)
+    for fv in ("0", "8", "10", "12", "13"):  # plain, generated chain, with its LDS loads/stores, rescheduled (12 = production)
         monkeypatch.setenv("EKFVIO_POTRF_FV", fv)
         st = (C.c_int64 * 80)()
         assert g.lib.ekfvio_test_potrf_stamps(g.h, st) == capi.OK
         hashes.append((st[12], st[13]))
-    assert hashes[0] == hashes[1] == hashes[2] and hashes[0][0] != 0
+    assert all(h == hashes[0] for h in hashes) and hashes[0][0] != 0
     g.close()
 
 
