@@ -115,6 +115,22 @@ __device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G
 #endif
     }
 }
+// The sign mask of a block column is requested like the tiles: a VECTOR load (every lane the same address), so that it
+// retires under the same vmcnt wait as the tile loads issued behind it.  As a scalar load it sat on lgkmcnt with the LDS
+// traffic and its cold-L2 latency (the mask was written by the previous launch, on another compute unit) landed on the
+// chain: 2.3 us per filter step at N = 256 (same-box A/B, scripts/ab_lib.py).  sign_mask_request before the tile loads,
+// sign_mask_value after the barrier that follows them.
+__device__ __forceinline__ unsigned long long sign_mask_request(const unsigned long long* p) {
+    unsigned long long v;
+    const unsigned zero = 0u;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(zero), "s"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned long long sign_mask_value(unsigned long long v) {
+    asm volatile("" : "+v"(v));  // every use stays behind the wait that precedes this point
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 // a panel block of the identity rows with the column signs of its block column applied (the gain GEMM K = Y S U^-1 takes
 // S from here; `neg` is zero unless the block had negative pivots)
 __device__ __forceinline__ void store_tile_signed(const float* T, float* __restrict__ G, int ld, int tid, unsigned long long neg) {
@@ -179,8 +195,9 @@ __device__ __forceinline__ f32x16 mma64(const float* As, int a_si, int a_sq, con
 }
 // The same product with the column signs of an indefinite block applied to A's k index (bit q of `neg` set: column q
 // of the panel belongs to a negative pivot): sum_q s_q A(i,q) B(j,q).  Rare path (see the header).
-__device__ __forceinline__ f32x16 mma64_signed(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int wr,
-                                               int wc, int lane, unsigned long long neg) {
+// Not inlined: the rare path must not shape the register allocation and scheduling of the kernels' hot loops.
+__device__ __attribute__((noinline)) f32x16 mma64_signed(const float* As, int a_si, int a_sq, const float* Bs, int b_sj, int b_sq, int wr,
+                                                         int wc, int lane, unsigned long long neg) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -470,7 +487,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
 // elimination on wavefront 0 (one matrix row per lane, the tile in LDS), then the four 16x16 inverses of U's diagonal
 // blocks, one per wavefront.  A must hold the lower triangle of the ORIGINAL tile again (callers rebuild it).  Returns
 // the mask of negative pivots (uniform over the workgroup).  A pivot of magnitude below 1e-20 is treated as +-1e-20.
-__device__ __forceinline__ unsigned long long potrf64_signed(float* A, float* Tinv, int tid) {
+__device__ __attribute__((noinline)) unsigned long long potrf64_signed(float* A, float* Tinv, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     __syncthreads();
     if (wave == 0) {
@@ -637,7 +654,8 @@ struct SchurArgs {
     int ldk = 0;
     int nb = 0;           // X row blocks = n_pad / 64
 };
-template <bool SOLVE>
+// SCHUR = false compiles every Schur-tile branch away: the default flow's kernel is the plain sweep step.
+template <bool SOLVE, bool SCHUR = false>
 __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
                                                         float* __restrict__ Linv, int k, int mb, int idb0, int* info,
                                                         unsigned long long* Lsign, long long* dbg, SchurArgs sc) {
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     // 256th double up on the compute units of the first ones, so in a larger grid the chain trades places with workgroup
     // 255, whose compute unit is the last to receive a second resident.
     int t = blockIdx.x;
-    if (SOLVE && rr > 0 && gridDim.x > 256) {
+    if (SCHUR && rr > 0 && gridDim.x > 256) {
         if (t == 0) t = 255;
         else if (t == 255) t = 0;
     }
@@ -676,7 +694,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
         i = k + 1 + ii;
         j = k + 1 + (t - ii * (ii + 1) / 2);
-    } else if (t < ntri + rb * rr) {
+    } else if (!SCHUR || t < ntri + rb * rr) {
         t -= ntri;
         i = mb + t / rr;
         j = k + 1 + t % rr;
@@ -700,13 +718,17 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
 
     // negative pivots of block column k (zero unless diagonal tile k went through the U S U^T path): a scalar load
-    const unsigned long long neg = Lsign[k];
+    unsigned long long neg = sign_mask_request(Lsign + k);
     if (SOLVE) {
         load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
         load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
         load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
         if (i != j) load_tile(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
         __syncthreads();
+        neg = sign_mask_value(neg);
+#ifdef EKF_NO_SIGNED  // diagnostic build: prices the hooks of the rare path (scripts/ab_lib.py)
+        neg = 0ull;
+#endif
         CSTAMP(1);
         if (i != j)
             tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_jk
@@ -715,7 +737,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         __syncthreads();
         CSTAMP(2);
         // the panel blocks of the extra rows are results of their own only without Schur tiles (the gain GEMM reads them)
-        if (kind == 0 && j == k + 1 && (i < mb || sc.P == nullptr)) {
+        if (kind == 0 && j == k + 1 && (i < mb || !SCHUR)) {
             float* dst = L + (size_t)k * PB * ldl + (size_t)i * PB;
             if (neg != 0ull && i >= idb0) store_tile_signed(Ti, dst, ldl, tid, neg);  // identity rows carry S into the gain
             else store_tile(Ti, dst, ldl, tid);
@@ -724,13 +746,14 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         load_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
         if (i != j) load_tile(Tj, L + (size_t)k * PB * ldl + (size_t)j * PB, ldl, tid);
         __syncthreads();
+        neg = sign_mask_value(neg);
     }
     // A_ij(r,s) -= sum_c L_ik(r,c) L_jk(s,c)
     const float* Bj = (i != j) ? Tj : Ti;
     // where the tile's target lives: the augmented matrix itself, Sigma (T tiles) or the gain (K tiles)
     float* Sij;
     int ldt;
-    if (kind == 0) {
+    if (!SCHUR || kind == 0) {
         Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
         ldt = lds;
     } else if (kind == 1) {
@@ -800,7 +823,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
             if (bad) atomicOr(info, 1);
         }
         CSTAMP(5);
-    } else if (kind == 2) {
+    } else if (SCHUR && kind == 2) {
         // K(a,c) = sum_k Y_ak S_k Z_ck^T: the first step that reaches identity block row c stores, later ones add
         const bool first = (j - idb0) == k;
         float tv[16];
@@ -824,7 +847,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
             tv[q] = Sij[(size_t)c * ldt + r];
         }
         float tm[16];
-        if (kind == 1 && i != j) {
+        if (SCHUR && kind == 1 && i != j) {
             // the mirror image T(b,a) -= (Y_ak S Y_bk^T)^T from the same product: transposed through LDS (L_kk's tile is
             // free: every wavefront is past its substitution), then read back with the lanes along the mirror tile's rows
             float* Mji = sc.P + (size_t)(i - mb) * PB * sc.ldp + (size_t)(j - mb) * PB;
@@ -863,13 +886,14 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const float* __restrict
     const int b = blockIdx.x;
     const int i = (b < na) ? k + 1 + b : mb + (b - na);
     if (i >= idb0 && i - idb0 > k) return;  // identity block row: block (i,k) is still zero and stays unused
+    unsigned long long neg = sign_mask_request(Lsign + k);
     load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
     load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
     load_tile(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
     __syncthreads();
+    neg = sign_mask_value(neg);
     tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
     __syncthreads();
-    const unsigned long long neg = Lsign[k];
     if (sign_irows && neg != 0ull && i >= idb0) store_tile_signed(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid, neg);
     else store_tile(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
 }
@@ -1207,8 +1231,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         for (int k = 0; k < mb; k++) {
             const int r = mb - 1 - k;
             const dim3 grid(r * (r + 1) / 2 + rb * r + nT + sc.nb * (k + 1));
-            hipLaunchKernelGGL(chol_step_kernel<true>, grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0, f->info,
-                               f->Lsign, f->sweep_dbg, sc);
+            hipLaunchKernelGGL((chol_step_kernel<true, true>), grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0,
+                               f->info, f->Lsign, f->sweep_dbg, sc);
         }
         return;
     }

@@ -179,6 +179,7 @@ struct ekfvio_filter {
 //          receives K*y.
 //  mode 2  Sigma' = T + G K^T: workgroup (0,0) also finishes the mean: mu += column n,
 //          quaternion renormalised (:600-609), column n zeroed again, frame counter advanced.
+//  mode 3  the same, K y taken from per-column-block partial sums (Schur flow).
 struct GemmEpi {
     int mode = 0;
     const int* inv_idx = nullptr;
@@ -187,7 +188,7 @@ struct GemmEpi {
     int ldg = 0;
     float* mu = nullptr;
     float* Pcol = nullptr;  // column n of P
-    const float* Kyp = nullptr;  // non-null: K y as `kyp_blocks` partial sums (rows of ld kyp_ld), added in order, instead of Pcol
+    const float* Kyp = nullptr;  // mode 3: K y as `kyp_blocks` partial sums (rows of ld kyp_ld), added in order, instead of Pcol
     int kyp_blocks = 0, kyp_ld = 0;
     int n = 0;
     int* frame_counter = nullptr;

@@ -965,6 +965,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather, true);
         launch_joseph_g(f, m, m_pad, n_pad, m_on_device);
         ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad, 1);
+        e2.mode = 3;  // the mean takes K y from joseph_g_kernel's partial sums
         e2.Kyp = f->Wt;
         e2.kyp_blocks = m_pad / 64;
         e2.kyp_ld = ld;

@@ -299,12 +299,13 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
             if (q >= 0 && j < N && i < M) epi.G[(size_t)q * epi.ldg + i] = kr - vout[r];
         }
     }
-    if (EPI == 2 && blockIdx.x == 0 && blockIdx.y == 0 && epi.n > 0) {
-        // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
+    if ((EPI == 2 || EPI == 3) && blockIdx.x == 0 && blockIdx.y == 0 && epi.n > 0) {
+        // mu += K*y, quaternion renormalised.  EPI 2: K*y is column n of P, left there by the mode-1 GEMM; EPI 3 (Schur
+        // flow): it arrives as per-column-block partial sums (joseph_g_kernel), added here in block order
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256 * GROUPS) {
             float v;
-            if (epi.Kyp) {  // K y arrives as per-column-block partial sums (joseph_g_kernel): added in block order
+            if (EPI == 3) {
                 float ky = epi.Kyp[e];
                 for (int cb = 1; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
                 v = epi.mu[e] + ky;
@@ -648,12 +649,13 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             }
         }
     }
-    if (EPI == 2 && i0 == 0 && j0 == 0 && epi.n > 0) {
-        // mu += K*y (column n of P, left there by the mode-1 GEMM), quaternion renormalised
+    if ((EPI == 2 || EPI == 3) && i0 == 0 && j0 == 0 && epi.n > 0) {
+        // mu += K*y, quaternion renormalised.  EPI 2: K*y is column n of P, left there by the mode-1 GEMM; EPI 3 (Schur
+        // flow): it arrives as per-column-block partial sums (joseph_g_kernel), added here in block order
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256) {
             float v;
-            if (epi.Kyp) {  // K y arrives as per-column-block partial sums (joseph_g_kernel): added in block order
+            if (EPI == 3) {
                 float ky = epi.Kyp[e];
                 for (int cb = 1; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
                 v = epi.mu[e] + ky;
@@ -734,6 +736,7 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
     } while (0)
         if (e.mode == 1) GEMM16_BM(2, 1);
         else if (e.mode == 2) GEMM16_BM(2, 2);
+        else if (e.mode == 3) GEMM16_BM(2, 3);
         else if (wps == 2) GEMM16_BM(2, 0);
         else GEMM16_BM(1, 0);
 #undef GEMM16_BM
@@ -749,6 +752,8 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         GEMM_GO(true, 1, 1);  // the Joseph GEMMs are always A * B^T
     } else if (e.mode == 2) {
         GEMM_GO(true, 1, 2);
+    } else if (e.mode == 3) {
+        GEMM_GO(true, 1, 3);
     } else if (groups == 2) {
         if (transB) GEMM_GO(true, 2, 0);
         else GEMM_GO(false, 2, 0);
