@@ -228,6 +228,40 @@ def klt_cpu_baseline(n_points):
             "sample": "2 pyramids + %d x %d tracks, window 21, levels 0-3, 30 it / 0.01 (KLTTracker.cpp:61-64)" % (reps, n_points)}
 
 
+def concurrent_sequences(n_landmarks, device, sequences, steps, dt_warm=10):
+    """Several independent sequences on ONE GPU, each its own handle and stream, their graph replays in flight together:
+    what the idle compute units are worth when a single filter step is one workgroup's latency.  (Config 4 itself is one
+    sequence per GPU; this is reported next to it, never as `value`.)"""
+    from ekf_vio_amd import TightlyCoupledEKF
+    from ekf_vio_amd.sim import Scenario
+    hs = []
+    for s in range(sequences):
+        sc = Scenario(n_landmarks, seed=100 + s)
+        g = TightlyCoupledEKF(max_features=n_landmarks, device=device)
+        g.addNewFeatures(sc.initial_features())
+        fr = list(sc.frames(dt_warm + steps))
+        g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+        g.run_uploaded(0, 0, sc.dt)
+        hs.append((g, sc))
+    for g, sc in hs:
+        g.run_uploaded(0, dt_warm, sc.dt)
+    for g, sc in hs:
+        g.synchronize()
+    for g, sc in hs:
+        g.run_uploaded(dt_warm, 0, sc.dt)
+    t0 = time.perf_counter()
+    for g, sc in hs:
+        g.run_uploaded(dt_warm, steps, sc.dt)
+    for g, sc in hs:
+        g.synchronize()
+    el = time.perf_counter() - t0
+    ok = all(bool(np.isfinite(g.base_mu).all()) for g, _ in hs)
+    for g, _ in hs:
+        g.close()
+    return {"sequences": sequences, "steps_each": steps, "total_steps_per_s": sequences * steps / el,
+            "per_sequence_steps_per_s": steps / el, "states_finite": ok}
+
+
 def step_flops(N):
     """Algorithmic flops the step executes (dense form of the update, structured predict), DESIGN.md section 4."""
     n, m = 22 + 3 * N, 2 * N
@@ -364,6 +398,11 @@ def main():
             extra["roofline_stress_shape"] = {"error": str(ex)}
         extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
     g.close()
+    if rank == 0 and world == 1 and not args.no_full_loop:
+        try:
+            extra["concurrent_sequences_one_gpu"] = [concurrent_sequences(N, local, b, min(args.steps, 200)) for b in (2, 4, 8)]
+        except Exception as ex:  # an extra, never fatal
+            extra["concurrent_sequences_one_gpu"] = {"error": repr(ex)}
     if rank == 0:
         if world == 1 and not args.no_full_loop:
             try:
