@@ -160,6 +160,31 @@ __device__ __forceinline__ void store_tile_lower(const float* T, float* __restri
 #endif
     }
 }
+// Columns C0 .. C0+NC-1 of a tile by NT threads (t = 0 .. NT-1): what wavefronts without work in a phase of the 64x64
+// factorisation store while wavefront 0 runs its pivot chain (potrf64_lds, `idle`).  LOWER: zero above the diagonal.
+template <int C0, int NC, int NT, bool LOWER>
+__device__ __forceinline__ void store_cols(const float* T, float* __restrict__ G, int ld, int t) {
+    static_assert(PLD % 4 == 0, "vector LDS reads");
+#pragma unroll
+    for (int it = 0; it < (NC * 16 + NT - 1) / NT; it++) {
+        const int e = t + it * NT;
+        if ((NC * 16) % NT != 0 && e >= NC * 16) break;
+        const int c = C0 + (e >> 4), r4 = (e & 15) * 4;
+        const float4 q = *reinterpret_cast<const float4*>(T + c * PLD + r4);
+        *reinterpret_cast<float4*>(G + (size_t)c * ld + r4) =
+            LOWER ? make_float4(r4 >= c ? q.x : 0.f, r4 + 1 >= c ? q.y : 0.f, r4 + 2 >= c ? q.z : 0.f, r4 + 3 >= c ? q.w : 0.f) : q;
+    }
+}
+// inverse blocks P0 .. P0+NP-1, thread t = 0 .. 64*NP-1
+__device__ __forceinline__ void store_inv_blocks(const float* Tinv, float* __restrict__ G, int p0, int t) {
+    const int p = p0 + (t >> 6), c = (t >> 2) & 15, r4 = (t & 3) * 4;
+    const float* s = Tinv + p * 16 * ILD + c * ILD + r4;
+    *reinterpret_cast<float4*>(G + (p0 * 64 + t) * 4) = make_float4(s[0], s[1], s[2], s[3]);
+}
+struct NoIdleWork {
+    template <class PC>
+    __device__ __forceinline__ void operator()(PC, int) const {}
+};
 // four 16x16 inverse blocks (global: block p at p*256, column-major ld 16) <-> LDS (stride ILD)
 __device__ __forceinline__ void load_inv(float* Tinv, const float* __restrict__ G, int tid) {
     const float4 v = *reinterpret_cast<const float4*>(G + tid * 4);
@@ -380,8 +405,11 @@ __device__ __forceinline__ void potrf_inverse16(const float* A, float* Tinv, int
 
 #include "potrf_chain.inc"
 
-template <int FV = EKF_POTRF_FV>
-__device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long long* stamps = nullptr) {
+// idle(integral_constant<p>, wave): called by wavefronts 1-3 in phase F of panel p after their own share of it.  Columns
+// left of panel p and the inverses of the blocks before p are final by then (read-only for everyone): a caller can have
+// them stored while the chain runs (waves 2-3 are free in phase F of panel 2, waves 1-3 in that of panel 3).
+template <int FV = EKF_POTRF_FV, class Idle = NoIdleWork>
+__device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long long* stamps = nullptr, Idle idle = Idle()) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     bool bad = false;
@@ -465,6 +493,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
         } else if (p == 2) {
             if (wave == 1) potrf_tile_update(A, 16, 1, 1, lane);
         }
+        if (wave != 0) idle(pc, wave);
         POTRF_WSTAMP(2 * p);
         __syncthreads();
         POTRF_STAMP(2 + 2 * p);
@@ -602,7 +631,18 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
     }
     __syncthreads();
     GSTAMP_(1);
-    const bool bad = potrf64_lds(A, Tinv, tid);
+    const float* A_c = A;
+    const float* Tinv_c = Tinv;
+    auto idle = [&](auto pc, int wv) {  // finished columns and inverses are stored under the pivot chain (see chol_step_kernel)
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p == 2) {
+            if (wv >= 2) store_cols<0, 32, 128, true>(A_c, L, ldl, tid - 128);
+        } else if constexpr (p == 3) {
+            store_cols<32, 16, 192, true>(A_c, L, ldl, tid - 64);
+            store_inv_blocks(Tinv_c, Linv, 0, tid - 64);
+        }
+    };
+    const bool bad = potrf64_lds<EKF_POTRF_FV>(A, Tinv, tid, nullptr, idle);
     unsigned long long neg = 0ull;
     if (bad) {  // workgroup-uniform, rare: the tile is gathered again (its loads were consumed) and factored as U S U^T
         __syncthreads();
@@ -612,10 +652,14 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
             A[c * PLD + r] = gather_a_elem(ga.P[(size_t)ir[ps] * ga.ld + sc], r, c, m, rd[ps], ro[ps]);
         }
         neg = potrf64_signed(A, Tinv, tid);
+        GSTAMP_(2);
+        store_tile_lower(A, L, ldl, tid);
+        store_inv(Tinv, Linv, tid);
+    } else {
+        GSTAMP_(2);
+        store_cols<48, 16, 256, true>(A_c, L, ldl, tid);
+        if (tid < 64) store_inv_blocks(Tinv_c, Linv, 3, tid);
     }
-    GSTAMP_(2);
-    store_tile_lower(A, L, ldl, tid);
-    store_inv(Tinv, Linv, tid);
     if (tid == 0) {
         Lsign[0] = neg;
         if (bad) atomicOr(info, 1);
@@ -737,7 +781,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         __syncthreads();
         CSTAMP(2);
         // the panel blocks of the extra rows are results of their own only without Schur tiles (the gain GEMM reads them)
-        if (kind == 0 && j == k + 1 && (i < mb || !SCHUR)) {
+        // (the chain workgroup stores its panel block later, from wavefronts that idle during the factorisation)
+        if (kind == 0 && j == k + 1 && (i < mb || !SCHUR) && !chain) {
             float* dst = L + (size_t)k * PB * ldl + (size_t)i * PB;
             if (neg != 0ull && i >= idb0) store_tile_signed(Ti, dst, ldl, tid, neg);  // identity rows carry S into the gain
             else store_tile(Ti, dst, ldl, tid);
@@ -804,7 +849,26 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         }
         __syncthreads();
         CSTAMP(3);
-        const bool bad = potrf64_lds(Tl, Tinv, tid);
+        // Stores ride under the pivot chain: columns 0-31 of the factor by waves 2-3 in panel 2's phase, columns 32-47,
+        // the inverses of blocks 0-2 and this workgroup's panel block L_ik (SOLVE) by waves 1-3 in panel 3's; only the
+        // last 16 columns and the last inverse are left for the end.
+        float* Ldst = L + (size_t)j * PB * ldl + (size_t)i * PB;
+        float* Idst = Linv + (size_t)(k + 1) * PB * PB;
+        float* Pdst = L + (size_t)k * PB * ldl + (size_t)i * PB;
+        const float* Tl_c = Tl;
+        const float* Ti_c = Ti;
+        const float* Tinv_c = Tinv;
+        auto idle = [&](auto pc, int wv) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p == 2) {
+                if (wv >= 2) store_cols<0, 32, 128, true>(Tl_c, Ldst, ldl, tid - 128);
+            } else if constexpr (p == 3) {
+                store_cols<32, 16, 192, true>(Tl_c, Ldst, ldl, tid - 64);
+                store_inv_blocks(Tinv_c, Idst, 0, tid - 64);
+                if (SOLVE && (i < mb || !SCHUR)) store_cols<0, 64, 192, false>(Ti_c, Pdst, ldl, tid - 64);
+            }
+        };
+        const bool bad = potrf64_lds<EKF_POTRF_FV>(Tl, Tinv, tid, nullptr, idle);
         unsigned long long neg1 = 0ull;
         if (bad) {  // workgroup-uniform, rare: the updated tile is formed again and factored as U S U^T
             __syncthreads();
@@ -814,10 +878,14 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
                 Tl[c * PLD + r] = Sij[(size_t)c * lds + r] - up[q];
             }
             neg1 = potrf64_signed(Tl, Tinv, tid);
+            CSTAMP(4);
+            store_tile_lower(Tl, Ldst, ldl, tid);
+            store_inv(Tinv, Idst, tid);
+        } else {
+            CSTAMP(4);
+            store_cols<48, 16, 256, true>(Tl_c, Ldst, ldl, tid);
+            if (tid < 64) store_inv_blocks(Tinv_c, Idst, 3, tid);
         }
-        CSTAMP(4);
-        store_tile_lower(Tl, L + (size_t)j * PB * ldl + (size_t)i * PB, ldl, tid);
-        store_inv(Tinv, Linv + (size_t)(k + 1) * PB * PB, tid);
         if (tid == 0) {
             Lsign[k + 1] = neg1;
             if (bad) atomicOr(info, 1);

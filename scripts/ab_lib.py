@@ -1,5 +1,6 @@
 """Same-box A/B of two builds of the library: loads each .so given on the command line through ctypes (only entry points
-both rounds have), runs the N=256 closed loop from the device-resident sequence and prints steps/s (best of 3)."""
+both rounds have), runs the N=256 closed loop from the device-resident sequence and prints steps/s (best of 3) and a hash
+of the final covariance (builds that only re-schedule must agree bit for bit)."""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -40,5 +41,10 @@ for path in sys.argv[1:]:
         lib.ekfvio_run_uploaded(h, 20, steps, C.c_float(sc.dt))
         lib.ekfvio_synchronize(h)
         best = max(best, steps / (time.perf_counter() - t0))
-    print("%-60s %8.1f steps/s  (%.2f us/step)" % (os.path.basename(path), best, 1e6 / best), flush=True)
+    n = 22 + 3 * N
+    sig = np.zeros((n, n), np.float32)
+    lib.ekfvio_get_sigma.argtypes = [C.c_void_p, fp, C.c_int32]
+    assert lib.ekfvio_get_sigma(h, sig.ctypes.data_as(fp), n) == 0
+    import hashlib
+    print("%-40s %8.1f steps/s  (%.2f us/step)  Sigma sha1 %s" % (os.path.basename(path), best, 1e6 / best, hashlib.sha1(sig.tobytes()).hexdigest()[:12]), flush=True)
     lib.ekfvio_destroy(h)
