@@ -40,7 +40,7 @@ SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_r
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
            "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
            "ekfvio_profile_update_gemms", "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps", "ekfvio_test_sweep_stamps",
-           "ekfvio_test_cholesky_solve"]
+           "ekfvio_test_cholesky_solve", "ekfvio_test_klt_padded_level"]
 
 _lib = None
 
@@ -77,6 +77,7 @@ def load(build_if_missing=True):
         "ekfvio_klt_track_points": [vp, fp, fp, i32, fp, u8p],
         "ekfvio_klt_uncertainty_points": [vp, fp, fp, i32, fp],
         "ekfvio_klt_get_level": [vp, i32, ip, ip, u8p, C.POINTER(C.c_int16)],
+        "ekfvio_test_klt_padded_level": [vp, i32, ip, u8p, C.POINTER(C.c_int16)],
         "ekfvio_step_image": [vp, C.c_double, u8p, i32, i32, i32, fp], "ekfvio_imu": [vp, C.c_double, fp, fp], "ekfvio_imu_update": [vp, fp, fp],
         "ekfvio_replenish": [vp, ip, ip], "ekfvio_fast_detect": [vp, i32, i32, i32, ip, ip, ip], "ekfvio_test_blurred_level0": [vp, u8p],
         "ekfvio_upload_measurements": [vp, i32, fp, fp, u8p], "ekfvio_run_uploaded": [vp, i32, i32, f32],

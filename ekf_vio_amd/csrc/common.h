@@ -239,7 +239,7 @@ void launch_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[
 // fast.hip
 int fast_alloc(ekfvio_filter* f);
 void fast_free(ekfvio_filter* f);
-void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale);
+void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale, hipStream_t st);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
 int add_features_device(ekfvio_filter* f, int k);
 // The two P-update GEMM launches of an update with m measurement rows, `reps` times, into scratch (P2, Gm): the

@@ -406,9 +406,9 @@ void fast_free(ekfvio_filter* f) {
 }
 
 // Frame::Frame's cv::resize: f->staging (w x h, tightly packed) -> f->resized ((w/s) x (h/s))
-void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale) {
+void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale, hipStream_t st) {
     const int dw = w / inv_scale, dh = h / inv_scale;
-    hipLaunchKernelGGL(frame_resize_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, f->stream, f->staging, w, h, w, f->resized, dw,
+    hipLaunchKernelGGL(frame_resize_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, st, f->staging, w, h, w, f->resized, dw,
                        dh, (double)w / dw, (double)h / dh);
 }
 

@@ -14,15 +14,15 @@
 // geometry and a ZERO border.  With the borders materialised the tracker's inner loops are
 // branch-free: every window that passes OpenCV's bounds test lies inside the padded level.
 //
-// Kernels: klt_pad_kernel (upload -> padded level 0), klt_pyrdown_kernel (5x5 binomial,
-// integer, one thread per padded output pixel, coalesced row reads), klt_scharr_kernel,
-// and klt_track_kernel: one wavefront per landmark, all pyramid levels inside the kernel;
+// Kernels: klt_pyramid_kernel (all levels of a frame, padded images and Scharr derivatives, in
+// one launch) and klt_track_kernel: one wavefront per landmark, all pyramid levels inside the kernel;
 // the 21x21 window is spread over the 64 lanes (7 pixels per lane, template patch and
 // gradients in registers), the search region of the current frame is staged in LDS once
 // per level (re-staged only if the window walks out of it), and the per-iteration sums are
 // 64-bit wave reductions.
 #include <math.h>
 
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -64,43 +64,241 @@ __device__ __host__ inline int reflect101(int p, int len) {
     return p;
 }
 
-// One pyramid level in ONE launch: the padded image (reflect-101 border) and the Scharr derivatives of its
-// interior.  FIRST: level 0 from the frame itself; otherwise pyrDown of the previous padded level.  An interior
-// thread evaluates the level's pixel at its 3x3 neighbourhood itself (up to 9 x 25 taps: cheaper than a second
-// launch that re-reads the level), so a four-level pyramid is four launches instead of eight (pad, pyrDown x3,
-// Scharr x4).  pyrDown: [1 4 6 4 1]^2 / 256 with (v + 128) >> 8, BORDER_REFLECT_101 (the source level's border
-// supplies it); Scharr: 3/10/3, int16, zero outside the image.
-template <bool FIRST>
-__global__ void klt_level_kernel(const uint8_t* __restrict__ src, int spitch, uint8_t* __restrict__ dst, short* __restrict__ der, int w,
-                                 int h, int pitch) {
-    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
-    if (X >= w + 2 * KLT_BORDER) return;
-    auto val = [&](int xx, int yy) -> int {  // the level's pixel at reflect-101 coordinates
-        const int x = reflect101(xx, w), y = reflect101(yy, h);
-        if (FIRST) return src[(size_t)y * spitch + x];
-        const uint8_t* s = src + (size_t)(2 * y + KLT_BORDER) * spitch + 2 * x + KLT_BORDER;
+// The whole pyramid of a frame in ONE launch: padded images (reflect-101 borders) and Scharr derivatives of every level.
+// A workgroup owns a 32x32 tile of level 0 and the pixels of the coarser levels below it (16x16, 8x8, 4x4); it forms
+// every level it needs itself, out of LDS, on a region with a halo that shrinks with the level (22, 10, 4, 1 pixels:
+// h_l = 2 h_(l+1) + 2, the 5x5 pyrDown support of the next level's region, which ends with the 1-pixel ring Scharr
+// needs at the coarsest level).  Region entries hold the LEVEL's value at the reflect-101 image of their coordinate,
+// i.e. what the padded level holds there: level 0 entries are loaded through the reflected index; an out-of-image entry
+// of a coarser level is copied from the in-image entry it mirrors (always inside the same region: the halo is shorter
+// than the tile plus halo on the other side), NOT computed at its own position: pyrDown and reflection commute only when
+// the finer level's size is odd.  pyrDown: [1 4 6 4 1]^2 / 256 with (v + 128) >> 8 (exact integers, so the evaluation
+// order is free); Scharr: 3/10/3, int16, zero outside the image.  Every owned pixel is written to its own place and to
+// every border position that mirrors it (and a zero derivative there), so a level's padded planes are complete however
+// the frame size changed since the buffers were last used.
+// Was four launches, one per level (a thread per padded pixel, up to 9 x 25 taps each): 23-27 us of launch latency
+// per frame; the levels of a 640x480 frame are 300 workgroups of ~7 KB LDS here.
+#define PYR_T 32
+#define PYR_NT 512  // threads per workgroup: two wavefronts per SIMD, so one's LDS and memory latency hides under the other's arithmetic
+struct PyrOut {
+    uint8_t* img[4];
+    short* der[4];
+    int w[4], h[4], pitch[4];
+    int levels;
+};
+template <int L>
+struct PyrGeom {
+    static constexpr int H = (L == 0) ? 22 : (L == 1) ? 10 : (L == 2) ? 4 : 1;  // halo
+    static constexpr int T = PYR_T >> L;                                         // owned tile edge
+    static constexpr int S = T + 2 * H;                                          // region edge: 76, 36, 16, 6
+};
+// calls fn(X) for every X in [-KLT_BORDER, w + KLT_BORDER) other than x itself whose reflect-101 image is x (0 <= x < w)
+template <class F>
+__device__ __forceinline__ void for_mirror_images(int x, int w, F&& fn) {
+    if (w == 1) {
+        for (int X = -KLT_BORDER; X < 1 + KLT_BORDER; X++)
+            if (X != x) fn(X);
+        return;
+    }
+    const int P = 2 * (w - 1);
+    for (int X = x - ((x + KLT_BORDER) / P) * P; X < w + KLT_BORDER; X += P)
+        if (X != x) fn(X);
+    if (x != 0 && x != w - 1) {  // otherwise -x is in x's residue class
+        const int y = -x;        // y + KLT_BORDER may be negative: first member of the class at or above -KLT_BORDER
+        int X = (y >= -KLT_BORDER) ? y - ((y + KLT_BORDER) / P) * P : y + ((-KLT_BORDER - y + P - 1) / P) * P;
+        for (; X < w + KLT_BORDER; X += P) fn(X);
+    }
+}
+// Border copies of a tile's pixels for a level narrower or lower than two borders plus two (several reflections can land
+// on one pixel): small frames and crops only, kept out of line.
+__device__ __attribute__((noinline)) void pyr_emit_border_general(const uint8_t* R, int S, int H, int T, int w, int h, int pitch,
+                                                                  uint8_t* img, short* der, int ax, int ay, int tid) {
+    for (int e = tid; e < T * T; e += PYR_NT) {
+        const int lx = e % T, ly = e / T;
+        const int x = ax + lx, y = ay + ly;
+        if (x >= w || y >= h) continue;
+        const uint8_t c1 = R[(ly + H) * S + lx + H];
+        auto put = [&](int X, int Y) {
+            const size_t at = (size_t)(Y + KLT_BORDER) * pitch + (X + KLT_BORDER);
+            img[at] = c1;
+            *reinterpret_cast<int*>(der + at * 2) = 0;
+        };
+        for_mirror_images(x, w, [&](int X) { put(X, y); });
+        for_mirror_images(y, h, [&](int Y) {
+            put(x, Y);
+            for_mirror_images(x, w, [&](int X) { put(X, Y); });
+        });
+    }
+}
+template <int L>
+__device__ __forceinline__ void pyr_emit_level(const uint8_t* R, const PyrOut& o, int tx, int ty, int tid) {
+    using G = PyrGeom<L>;
+    constexpr int B = KLT_BORDER;
+    const int w = o.w[L], h = o.h[L], pitch = o.pitch[L];
+    const int ax = tx * G::T, ay = ty * G::T;
+    uint8_t* img = o.img[L];
+    short* der = o.der[L];
+    // A level at least two borders plus two wide has at most ONE mirror image per pixel and axis in the border: x in [1, B]
+    // at -x, x in [w-1-B, w-2] at 2(w-1)-x.  Then an owned pixel goes to its own place and, if the tile lies near an edge
+    // of the image (workgroup-uniform), to up to three border positions (image byte, zero derivative).
+    const bool wide = w >= 2 * B + 2 && h >= 2 * B + 2;
+    const bool edge = wide && (ax <= B || ax + G::T - 1 >= w - 1 - B || ay <= B || ay + G::T - 1 >= h - 1 - B);
+#pragma unroll
+    for (int it = 0; it < (G::T * G::T + PYR_NT - 1) / PYR_NT; it++) {
+        const int e = tid + PYR_NT * it;
+        const int lx = e % G::T, ly = e / G::T;
+        const int x = ax + lx, y = ay + ly;
+        if (e < G::T * G::T && x < w && y < h) {
+            // the 3x3 neighbourhood as three byte windows cut out of aligned dword pairs (3 LDS reads instead of 9)
+            const unsigned* R32 = reinterpret_cast<const unsigned*>(R);
+            const int o0 = (ly + G::H - 1) * G::S + lx + G::H - 1;
+            unsigned rw[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int ob = o0 + r * G::S;
+                rw[r] = __builtin_amdgcn_alignbyte(R32[(ob >> 2) + 1], R32[ob >> 2], ob & 3);
+            }
+            const int u0 = rw[0] & 0xff, u1 = (rw[0] >> 8) & 0xff, u2 = (rw[0] >> 16) & 0xff;
+            const int c0 = rw[1] & 0xff, c1 = (rw[1] >> 8) & 0xff, c2 = (rw[1] >> 16) & 0xff;
+            const int d0 = rw[2] & 0xff, d1 = (rw[2] >> 8) & 0xff, d2 = (rw[2] >> 16) & 0xff;
+            const int t0m = (u0 + d0) * 3 + c0 * 10, t0p = (u2 + d2) * 3 + c2 * 10;
+            const int t1m = d0 - u0, t1c = d1 - u1, t1p = d2 - u2;
+            const size_t at = (size_t)(y + B) * pitch + (x + B);
+            img[at] = (uint8_t)c1;
+            short2 g;
+            g.x = (short)(t0p - t0m);
+            g.y = (short)((t1p + t1m) * 3 + t1c * 10);
+            *reinterpret_cast<short2*>(der + at * 2) = g;
+            if (edge) {
+                const int X = (x >= 1 && x <= B) ? -x : ((x >= w - 1 - B && x <= w - 2) ? 2 * (w - 1) - x : x);
+                const int Y = (y >= 1 && y <= B) ? -y : ((y >= h - 1 - B && y <= h - 2) ? 2 * (h - 1) - y : y);
+                const size_t ax_ = (size_t)(y + B) * pitch + (X + B), ay_ = (size_t)(Y + B) * pitch + (x + B),
+                             axy = (size_t)(Y + B) * pitch + (X + B);
+                if (X != x) {
+                    img[ax_] = (uint8_t)c1;
+                    *reinterpret_cast<int*>(der + ax_ * 2) = 0;
+                }
+                if (Y != y) {
+                    img[ay_] = (uint8_t)c1;
+                    *reinterpret_cast<int*>(der + ay_ * 2) = 0;
+                }
+                if (X != x && Y != y) {
+                    img[axy] = (uint8_t)c1;
+                    *reinterpret_cast<int*>(der + axy * 2) = 0;
+                }
+            }
+        }
+    }
+    if (!wide) pyr_emit_border_general(R, G::S, G::H, G::T, w, h, pitch, img, der, ax, ay, tid);
+}
+// region of level L (Rd) from the region of level L-1 (Rs)
+template <int L>
+__device__ __forceinline__ void pyr_down_level(const uint8_t* Rs, uint8_t* Rd, const PyrOut& o, int tx, int ty, int tid) {
+    using G = PyrGeom<L>;
+    using Gs = PyrGeom<L - 1>;
+    const int w = o.w[L], h = o.h[L];
+    const int ox = tx * G::T - G::H, oy = ty * G::T - G::H;
+    for (int e = tid; e < G::S * G::S; e += PYR_NT) {
+        const int jx = e % G::S, jy = e / G::S;
+        const int qx = ox + jx, qy = oy + jy;
+        if (qx < 0 || qx >= w || qy < 0 || qy >= h) continue;
+        // source rows 2 jy .. 2 jy + 4, bytes 2 jx .. 2 jx + 4 of each (the entry for (2 qx, 2 qy) is at (2 jy + 2, 2 jx + 2)):
+        // a five-byte window at an even offset lies inside one aligned dword pair
+        const unsigned* Rs32 = reinterpret_cast<const unsigned*>(Rs);
+        const int o0 = 2 * jy * Gs::S + 2 * jx;
         int v = 0;
 #pragma unroll
-        for (int j = -2; j <= 2; j++) {
-            const uint8_t* r = s + j * spitch;
-            const int rs = r[-2] + r[2] + 4 * (r[-1] + r[1]) + 6 * r[0];
-            const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+        for (int j = 0; j < 5; j++) {
+            const int ob = o0 + j * Gs::S;
+            const unsigned d0 = Rs32[ob >> 2], d1 = Rs32[(ob >> 2) + 1];
+            const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, ob & 3);
+            const unsigned b4 = ((ob & 2) ? (d1 >> 16) : d1) & 0xff;
+            const int rs = (int)((lo & 0xff) + b4 + 4 * (((lo >> 8) & 0xff) + (lo >> 24)) + 6 * ((lo >> 16) & 0xff));
+            const int wj = (j == 2) ? 6 : ((j == 1 || j == 3) ? 4 : 1);
             v += wj * rs;
         }
-        return (v + 128) >> 8;
-    };
-    const int x = X - KLT_BORDER, y = Y - KLT_BORDER;
-    const int c11 = val(x, y);
-    dst[(size_t)Y * pitch + X] = (uint8_t)c11;
-    if (x < 0 || x >= w || y < 0 || y >= h) return;
-    const int u0 = val(x - 1, y - 1), u1 = val(x, y - 1), u2 = val(x + 1, y - 1);
-    const int c0 = val(x - 1, y), c2 = val(x + 1, y);
-    const int d0 = val(x - 1, y + 1), d1 = val(x, y + 1), d2 = val(x + 1, y + 1);
-    const int t0m = (u0 + d0) * 3 + c0 * 10, t0p = (u2 + d2) * 3 + c2 * 10;
-    const int t1m = d0 - u0, t1c = d1 - u1, t1p = d2 - u2;
-    short* o = der + ((size_t)Y * pitch + X) * 2;
-    o[0] = (short)(t0p - t0m);
-    o[1] = (short)((t1p + t1m) * 3 + t1c * 10);
+        Rd[e] = (uint8_t)((v + 128) >> 8);
+    }
+    __syncthreads();
+    // a region that lies inside the level (workgroup-uniform) has no mirrored entries
+    if (ox >= 0 && oy >= 0 && ox + G::S <= w && oy + G::S <= h) return;
+    for (int e = tid; e < G::S * G::S; e += PYR_NT) {
+        const int jx = e % G::S, jy = e / G::S;
+        const int qx = ox + jx, qy = oy + jy;
+        if (qx >= 0 && qx < w && qy >= 0 && qy < h) continue;
+        const int rx = reflect101(qx, w), ry = reflect101(qy, h);
+        Rd[e] = Rd[(ry - oy) * G::S + (rx - ox)];
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __restrict__ src, int spitch, PyrOut o, long long* dbg) {
+    // diagnostic phase stamps of one interior workgroup (scripts/klt_timing.py); dbg is null in production
+#define PSTAMP(slot)                                                                                                     \
+    do {                                                                                                                 \
+        if (dbg && blockIdx.x == 5 && blockIdx.y == 5 && threadIdx.x == 0) dbg[940 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    PSTAMP(0);
+    const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;
+    if (dbg && threadIdx.x == 0 && wg_ < 450) dbg[2 * wg_] = (long long)__builtin_amdgcn_s_memrealtime();
+    // regions are read through aligned dword pairs: 8 bytes of slack behind each (a window's second dword may lie past the end)
+    __shared__ __attribute__((aligned(8))) uint8_t R0[PyrGeom<0>::S * PyrGeom<0>::S + 8];
+    __shared__ __attribute__((aligned(8))) uint8_t R1[PyrGeom<1>::S * PyrGeom<1>::S + 8];
+    __shared__ __attribute__((aligned(8))) uint8_t R2[PyrGeom<2>::S * PyrGeom<2>::S + 8];
+    __shared__ __attribute__((aligned(8))) uint8_t R3[PyrGeom<3>::S * PyrGeom<3>::S + 8];
+    const int tid = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y;
+    {
+        using G = PyrGeom<0>;
+        const int w = o.w[0], h = o.h[0];
+        const int ox = tx * G::T - G::H, oy = ty * G::T - G::H;
+        // Frames at least as large as the region: all loads of a thread in flight before the first LDS write, one reflection
+        // on either side, then a clamp for the region entries nothing reads (the region is 76 wide wherever the image
+        // ends).  Smaller frames take the general reflection, rolled.
+        constexpr int NL = (G::S * G::S + PYR_NT - 1) / PYR_NT;
+        if (w >= G::S && h >= G::S) {
+            uint8_t v[NL];
+#pragma unroll
+            for (int it = 0; it < NL; it++) {
+                const int e = min(tid + PYR_NT * it, G::S * G::S - 1);
+                const int px = ox + e % G::S, py = oy + e / G::S;
+                int rx = px < 0 ? -px : px;
+                rx = max(rx >= w ? 2 * w - 2 - rx : rx, 0);
+                int ry = py < 0 ? -py : py;
+                ry = max(ry >= h ? 2 * h - 2 - ry : ry, 0);
+                v[it] = src[(size_t)ry * spitch + rx];
+            }
+#pragma unroll
+            for (int it = 0; it < NL; it++) {
+                const int e = tid + PYR_NT * it;
+                if (e < G::S * G::S) R0[e] = v[it];
+            }
+        } else {
+#pragma unroll 1
+            for (int e = tid; e < G::S * G::S; e += PYR_NT)
+                R0[e] = src[(size_t)reflect101(oy + e / G::S, h) * spitch + reflect101(ox + e % G::S, w)];
+        }
+        __syncthreads();
+    }
+    PSTAMP(1);
+    pyr_emit_level<0>(R0, o, tx, ty, tid);
+    PSTAMP(2);
+    if (o.levels > 1) {
+        pyr_down_level<1>(R0, R1, o, tx, ty, tid);
+        PSTAMP(3);
+        pyr_emit_level<1>(R1, o, tx, ty, tid);
+    }
+    PSTAMP(4);
+    if (o.levels > 2) {
+        pyr_down_level<2>(R1, R2, o, tx, ty, tid);
+        pyr_emit_level<2>(R2, o, tx, ty, tid);
+    }
+    PSTAMP(5);
+    if (o.levels > 3) {
+        pyr_down_level<3>(R2, R3, o, tx, ty, tid);
+        pyr_emit_level<3>(R3, o, tx, ty, tid);
+    }
+    PSTAMP(6);
+    if (dbg && threadIdx.x == 0 && wg_ < 450) dbg[2 * wg_ + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#undef PSTAMP
 }
 
 // Exact sum over the wavefront of per-lane int32 partials (|v| < 2^28, so 8-lane sums fit in int32): a DPP
@@ -130,7 +328,10 @@ struct RowStage {
     __device__ inline void issue(const uint8_t* src, int pitch, int rows, int nbytes, int lane) {
         const unsigned long long a0 = (unsigned long long)src;
         shift = (int)(a0 & 3ull);
-        const unsigned* base = (const unsigned*)(a0 - shift);
+        // an integer -> pointer cast yields a generic pointer (flat_load: counted on lgkmcnt with the LDS traffic as well);
+        // the pyramid lives in global memory
+        typedef const __attribute__((address_space(1))) unsigned* global_u32;
+        const global_u32 base = (global_u32)(a0 - shift);
         const int nd = (shift + nbytes + 3) >> 2;  // dwords per row actually needed (<= LDP)
         const int pd = pitch >> 2;
 #pragma unroll
@@ -153,13 +354,30 @@ struct RowStage {
 #define KLT_TIP 8                                // dwords per LDS row of the template image (22 + 3 bytes -> 7)
 #define KLT_JP 11                                // dwords per LDS row of the search region (38 + 3 bytes -> 11)
 
-// One wavefront per point.  Mirrors LKTrackerInvoker; every scalar expression is evaluated
+// What findNewFeaturePositions does around calcOpticalFlowPyrLK, done by the point's own wavefront instead of a launch
+// before and one after the tracker (each ~4 us of launch latency for a few hundred flops):
+//   from_state: reference pixel from the last KLT result (previous frame's K) and initial guess from the predicted
+//               landmark (current frame's K) (KLTTracker.cpp:53-59);
+//   finish:     pass test with the kill box, pixel -> metric conversion and the constant measurement covariance of
+//               estimateUncertainty (:72-92, :100-106).  Off with the sample-based covariance, whose kernel runs between.
+struct TrackFuse {
+    const float* last_klt = nullptr;
+    const float* mu = nullptr;
+    float fxp = 0, fyp = 0, cxp = 0, cyp = 0, fxc = 0, fyc = 0, cxc = 0, cyc = 0;
+    int from_state = 0, finish = 0;
+    int w = 0, h = 0, kill_pad = 0;
+    float r0 = 0, r1 = 0;
+    float* z = nullptr;
+    float* R = nullptr;
+    uint8_t* pass = nullptr;
+};
+
+// One wavefront per point, three lanes per window row.  Mirrors LKTrackerInvoker; every scalar expression is evaluated
 // redundantly (and identically) by all 64 lanes.  Per level everything the wavefront reads from memory
 // (template image, its derivatives, the search region) is fetched with aligned 4-byte loads into LDS first;
 // the per-pixel work then runs out of LDS.
-__global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, const float* __restrict__ prev_px,
-                                                       float* next_px, uint8_t* status, int n, int win, int max_iter,
-                                                       float eps2, float min_eig, long long* dbg) {
+__global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, float* prev_px, float* next_px, uint8_t* status, int n,
+                                                       int win, int max_iter, float eps2, float min_eig, long long* dbg, TrackFuse tf) {
 #define KSTAMP(slot)                                                                                   \
     do {                                                                                               \
         if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[900 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
@@ -168,8 +386,6 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
     __shared__ unsigned regJ[KLT_RS * KLT_JP];         // search region of J, rows of aligned dwords
     __shared__ unsigned regI[KLT_TW * KLT_TIP];        // template image rows
     __shared__ unsigned regD[KLT_TW * KLT_TW];         // template derivatives, one (dx,dy) short pair per pixel
-    const uint8_t* regJb = (const uint8_t*)regJ;
-    const uint8_t* regIb = (const uint8_t*)regI;
     const int pt = blockIdx.x;
     const int lane = threadIdx.x;
     if (pt >= n) return;
@@ -177,21 +393,37 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
     const int W_BITS = 14;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float half = (win - 1) * 0.5f;
-    const int npix = win * win;
-    // slot geometry: pixel s = lane + 64*t  ->  (x, y) inside the window
-    int sx[KLT_SLOTS], sy[KLT_SLOTS];
+    // Lane geometry: three lanes per window row, each a run of `chunk` = ceil(win / 3) consecutive pixels of that row
+    // (win = 21: 63 lanes x 7 pixels).  A run's bilinear samples are chunk + 1 consecutive bytes of two image rows: two
+    // 8-byte windows cut out of aligned dwords (6 LDS reads) where a pixel-per-slot layout reads 4 bytes per pixel (28).
+    const int chunk = (win + 2) / 3;
+    const int lrow = min(lane / 3, win - 1), x0 = (lane % 3) * chunk;
     bool sv[KLT_SLOTS];
 #pragma unroll
-    for (int t = 0; t < KLT_SLOTS; t++) {
-        const int s = lane + 64 * t;
-        sv[t] = s < npix;
-        // s / win by reciprocal multiplication: exact for s < 448 and every odd window 3..21 (checked exhaustively)
-        const int q = (s * (65536 / win + 1)) >> 16;
-        sx[t] = sv[t] ? s - q * win : 0;
-        sy[t] = sv[t] ? q : 0;
+    for (int t = 0; t < KLT_SLOTS; t++) sv[t] = lane < 3 * win && t < chunk && x0 + t < win;
+    // bytes o .. o + 7 of an LDS byte array (o + 11 stays inside the staged row: see the row pitches)
+    auto window8 = [](const unsigned* base, int o, unsigned& w0, unsigned& w1) {
+        const unsigned d0 = base[o >> 2], d1 = base[(o >> 2) + 1], d2 = base[(o >> 2) + 2];
+        w0 = __builtin_amdgcn_alignbyte(d1, d0, o & 3);
+        w1 = __builtin_amdgcn_alignbyte(d2, d1, o & 3);
+    };
+    auto byte_of = [](unsigned w0, unsigned w1, int k) -> int { return (int)(((k < 4 ? w0 : w1) >> (8 * (k & 3))) & 0xffu); };
+    float ppx0, ppy0, ox, oy;
+    if (tf.from_state) {
+        ppx0 = tf.last_klt[2 * pt] * tf.fxp + tf.cxp;
+        ppy0 = tf.last_klt[2 * pt + 1] * tf.fyp + tf.cyp;
+        ox = tf.fxc * tf.mu[EKF_BASE + 3 * pt] + tf.cxc;
+        oy = tf.fyc * tf.mu[EKF_BASE + 3 * pt + 1] + tf.cyc;
+        if (lane == 0) {  // the sample-based covariance reads them
+            prev_px[2 * pt] = ppx0;
+            prev_px[2 * pt + 1] = ppy0;
+        }
+    } else {
+        ppx0 = prev_px[2 * pt];
+        ppy0 = prev_px[2 * pt + 1];
+        ox = next_px[2 * pt];
+        oy = next_px[2 * pt + 1];
     }
-    const float ppx0 = prev_px[2 * pt], ppy0 = prev_px[2 * pt + 1];
-    float ox = next_px[2 * pt], oy = next_px[2 * pt + 1];
     bool ok = true;
     for (int level = levels - 1; level >= 0; level--) {
         const LevelView I = P.lv[level];
@@ -248,16 +480,25 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int Iv[KLT_SLOTS], Ix[KLT_SLOTS], Iy[KLT_SLOTS];
         int pA11 = 0, pA12 = 0, pA22 = 0;  // per-lane partials: 7 terms of at most 4080^2 each
+        {
+            unsigned ia0, ia1, ib0, ib1;  // image rows lrow and lrow + 1, bytes x0 .. x0 + 7
+            const int oI = lrow * (KLT_TIP * 4) + shI + x0;
+            window8(regI, oI, ia0, ia1);
+            window8(regI, oI + KLT_TIP * 4, ib0, ib1);
+            unsigned dA[KLT_SLOTS + 1], dB[KLT_SLOTS + 1];  // derivative pairs of the same pixels
 #pragma unroll
-        for (int t = 0; t < KLT_SLOTS; t++) {
-            {   // slots past the window read pixel (0,0) and are zeroed below: no branch, all LDS reads in one batch
-                const uint8_t* ip = regIb + sy[t] * (KLT_TIP * 4) + shI + sx[t];
+            for (int t = 0; t <= KLT_SLOTS; t++) {
+                const int xc = min(x0 + t, KLT_TW - 1);  // runs of a short window's last lane: clamped, masked below
+                dA[t] = regD[lrow * KLT_TW + xc];
+                dB[t] = regD[(lrow + 1) * KLT_TW + xc];
+            }
+#pragma unroll
+            for (int t = 0; t < KLT_SLOTS; t++) {
                 // every factor fits 24 bits (pixels <= 255, weights <= 2^14, derivatives <= 4080, differences <= 8160):
                 // v_mul_i32_i24 / v_mad_i32_i24 run at full rate, v_mul_lo_u32 (what `*` compiles to) at a quarter
-                Iv[t] = descale(__mul24(ip[0], iw00) + __mul24(ip[1], iw01) + __mul24(ip[KLT_TIP * 4], iw10) +
-                                    __mul24(ip[KLT_TIP * 4 + 1], iw11), W_BITS - 5);
-                const unsigned d00 = regD[sy[t] * KLT_TW + sx[t]], d01 = regD[sy[t] * KLT_TW + sx[t] + 1];
-                const unsigned d10 = regD[(sy[t] + 1) * KLT_TW + sx[t]], d11 = regD[(sy[t] + 1) * KLT_TW + sx[t] + 1];
+                Iv[t] = descale(__mul24(byte_of(ia0, ia1, t), iw00) + __mul24(byte_of(ia0, ia1, t + 1), iw01) +
+                                    __mul24(byte_of(ib0, ib1, t), iw10) + __mul24(byte_of(ib0, ib1, t + 1), iw11), W_BITS - 5);
+                const unsigned d00 = dA[t], d01 = dA[t + 1], d10 = dB[t], d11 = dB[t + 1];
                 Ix[t] = descale(__mul24((short)(d00 & 0xffff), iw00) + __mul24((short)(d01 & 0xffff), iw01) +
                                     __mul24((short)(d10 & 0xffff), iw10) + __mul24((short)(d11 & 0xffff), iw11), W_BITS);
                 Iy[t] = descale(__mul24((short)(d00 >> 16), iw00) + __mul24((short)(d01 >> 16), iw01) +
@@ -305,13 +546,15 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
             iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int pb1 = 0, pb2 = 0;  // per-lane partials: 7 terms of at most 8160 * 4080 each
-            const int bx = inx - rx0 + shJ, by = iny - ry0;
+            {
+                unsigned ja0, ja1, jb0, jb1;  // search-region rows, bytes of the run and its right neighbour
+                const int oJ = (iny - ry0 + lrow) * (KLT_JP * 4) + inx - rx0 + shJ + x0;
+                window8(regJ, oJ, ja0, ja1);
+                window8(regJ, oJ + KLT_JP * 4, jb0, jb1);
 #pragma unroll
-            for (int t = 0; t < KLT_SLOTS; t++) {
-                {   // Ix = Iy = 0 in the slots past the window: their terms vanish
-                    const uint8_t* jp = regJb + (by + sy[t]) * (KLT_JP * 4) + bx + sx[t];
-                    const int diff = descale(__mul24(jp[0], iw00) + __mul24(jp[1], iw01) + __mul24(jp[KLT_JP * 4], iw10) +
-                                                 __mul24(jp[KLT_JP * 4 + 1], iw11), W_BITS - 5) - Iv[t];
+                for (int t = 0; t < KLT_SLOTS; t++) {  // Ix = Iy = 0 in the slots past the window: their terms vanish
+                    const int diff = descale(__mul24(byte_of(ja0, ja1, t), iw00) + __mul24(byte_of(ja0, ja1, t + 1), iw01) +
+                                                 __mul24(byte_of(jb0, jb1, t), iw10) + __mul24(byte_of(jb0, jb1, t + 1), iw11), W_BITS - 5) - Iv[t];
                     pb1 += __mul24(diff, Ix[t]);
                     pb2 += __mul24(diff, Iy[t]);
                 }
@@ -345,23 +588,19 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, con
         next_px[2 * pt] = ox;
         next_px[2 * pt + 1] = oy;
         status[pt] = ok ? 1 : 0;
+        if (tf.finish) {
+            const bool p = ok && !(ox < tf.kill_pad || oy < tf.kill_pad || tf.w - ox < tf.kill_pad || tf.h - oy < tf.kill_pad);
+            tf.pass[pt] = p ? 1 : 0;
+            tf.z[2 * pt] = p ? (ox - tf.cxc) / tf.fxc : 0.f;
+            tf.z[2 * pt + 1] = p ? (oy - tf.cyc) / tf.fyc : 0.f;
+            tf.R[4 * pt] = p ? tf.r0 : 0.f;
+            tf.R[4 * pt + 1] = 0.f;  // the off-diagonals of estimateUncertainty are zero, scaled or not
+            tf.R[4 * pt + 2] = 0.f;
+            tf.R[4 * pt + 3] = p ? tf.r1 : 0.f;
+        }
     }
 }
 
-// KLTTracker.cpp:53-59: reference pixels from the last KLT result (previous frame's K),
-// initial guesses from the EKF-predicted landmark positions (current frame's K).
-// Feature.h:60-66 indexes the column-major 3x3 K linearly, so K(2) and K(5) are the zero
-// entries K[2,0], K[2,1]: the principal point is ignored unless use_pp is set.
-__global__ void klt_points_kernel(const float* __restrict__ last_klt, const float* __restrict__ mu, int N, float fxp,
-                                  float fyp, float cxp, float cyp, float fxc, float fyc, float cxc, float cyc,
-                                  float* prev_px, float* next_px) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    prev_px[2 * i] = last_klt[2 * i] * fxp + cxp;
-    prev_px[2 * i + 1] = last_klt[2 * i + 1] * fyp + cyp;
-    next_px[2 * i] = fxc * mu[EKF_BASE + 3 * i] + cxc;
-    next_px[2 * i + 1] = fyc * mu[EKF_BASE + 3 * i + 1] + cyc;
-}
 
 // EKFVIO::publishPoints (EKFVIO.cpp:479-518): camera-frame point (u/rho, v/rho, 1/rho) per landmark -- p(2) = 1.0/p(2)
 // in double, narrowed, then two float products -- and the "intensity" channel f.img.at<uchar>(e.getPixel(f)): the byte
@@ -578,7 +817,7 @@ void klt_free(ekfvio_filter* f) {
 }
 
 // Device-side part of klt_push_frame: staging -> pyramid + derivatives of frames[cur]
-static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int w, int h) {
+static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int w, int h, hipStream_t st) {
     const int win = f->cfg.klt_window_size;
     fr.w[0] = w;
     fr.h[0] = h;
@@ -591,15 +830,16 @@ static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int
         fr.levels = l + 1;
     }
     ProfScope ps(f, PC_KLT_PYRAMID);
-    for (int l = 0; l < fr.levels; l++) {
-        const int pw = fr.w[l] + 2 * KLT_BORDER, ph = fr.h[l] + 2 * KLT_BORDER;
-        const dim3 grid((pw + 255) / 256, ph);
-        if (l == 0)
-            hipLaunchKernelGGL(klt_level_kernel<true>, grid, dim3(256), 0, f->stream, src, w, fr.img[0], fr.deriv[0], w, h, level_pitch(w));
-        else
-            hipLaunchKernelGGL(klt_level_kernel<false>, grid, dim3(256), 0, f->stream, fr.img[l - 1], level_pitch(fr.w[l - 1]), fr.img[l],
-                               fr.deriv[l], fr.w[l], fr.h[l], level_pitch(fr.w[l]));
+    PyrOut o;
+    o.levels = fr.levels;
+    for (int l = 0; l < 4; l++) {
+        o.img[l] = fr.img[l];
+        o.der[l] = fr.deriv[l];
+        o.w[l] = (l < fr.levels) ? fr.w[l] : 0;
+        o.h[l] = (l < fr.levels) ? fr.h[l] : 0;
+        o.pitch[l] = (l < fr.levels) ? level_pitch(fr.w[l]) : 0;
     }
+    hipLaunchKernelGGL(klt_pyramid_kernel, dim3((w + PYR_T - 1) / PYR_T, (h + PYR_T - 1) / PYR_T), dim3(PYR_NT), 0, st, src, w, o, f->sweep_dbg);
     return EKFVIO_OK;
 }
 
@@ -617,14 +857,14 @@ static void intrinsics(const ekfvio_filter* f, const float* K, float* fx, float*
     *cy = f->cfg.use_principal_point ? K[5] : 0.f;
 }
 
-static int track_points_device(ekfvio_filter* f, int n) {
+static int track_points_device(ekfvio_filter* f, int n, const TrackFuse& tf = TrackFuse()) {
     const KltFrame& prev = f->frames[f->cur ^ 1];
     const KltFrame& cur = f->frames[f->cur];
     const float eps = f->cfg.klt_epsilon;
     ProfScope ps(f, PC_KLT_TRACK);
     hipLaunchKernelGGL(klt_track_kernel, dim3(n), dim3(64), 0, f->stream, make_view(prev), make_view(cur), f->klt_prev_px,
                        f->klt_next_px, f->klt_status, n, f->cfg.klt_window_size, f->cfg.klt_max_iterations, eps * eps,
-                       f->cfg.klt_min_eigen, f->sweep_dbg);
+                       f->cfg.klt_min_eigen, f->sweep_dbg, tf);
     return EKFVIO_OK;
 }
 
@@ -652,28 +892,36 @@ int klt_track_device(ekfvio_filter* f) {
     float fxp, fyp, cxp, cyp, fxc, fyc, cxc, cyc;
     intrinsics(f, prev.K, &fxp, &fyp, &cxp, &cyp);
     intrinsics(f, cur.K, &fxc, &fyc, &cxc, &cyc);
-    hipLaunchKernelGGL(klt_points_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->last_klt, f->mu, N, fxp, fyp,
-                       cxp, cyp, fxc, fyc, cxc, cyc, f->klt_prev_px, f->klt_next_px);
-    track_points_device(f, N);
     // estimateUncertainty (:100-106) = 1e-5 I; scale = pow(1.0/K(0,0), 2) in double, narrowed
     const float r0 = 0.00001f * (float)pow(1.0 / (double)cur.K[0], 2);
     const float r1 = 0.00001f * (float)pow(1.0 / (double)cur.K[4], 2);
     const float s0 = (float)pow(1.0 / (double)cur.K[0], 2), s1 = (float)pow(1.0 / (double)cur.K[4], 2);
-    const float* cov_px = nullptr;
+    TrackFuse tf;
+    tf.last_klt = f->last_klt;
+    tf.mu = f->mu;
+    tf.fxp = fxp, tf.fyp = fyp, tf.cxp = cxp, tf.cyp = cyp, tf.fxc = fxc, tf.fyc = fyc, tf.cxc = cxc, tf.cyc = cyc;
+    tf.from_state = 1;
+    tf.finish = f->cfg.sample_based_uncertainty ? 0 : 1;
+    tf.w = cur.w[0], tf.h = cur.h[0], tf.kill_pad = f->cfg.kill_pad;
+    tf.r0 = r0, tf.r1 = r1;
+    tf.z = f->zmeas, tf.R = f->Rmeas, tf.pass = f->pass;
+    track_points_device(f, N, tf);
     if (f->cfg.sample_based_uncertainty) {  // estimateUncertaintySampleBased(lf, prev_fts[i], cf, new_fts[i])
         uncertainty_device(f, N);
-        cov_px = f->klt_cov_px;
+        hipLaunchKernelGGL(klt_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->klt_next_px, f->klt_status, N,
+                           cur.w[0], cur.h[0], f->cfg.kill_pad, fxc, fyc, cxc, cyc, r0, r1, f->klt_cov_px, s0, s1, f->zmeas,
+                           f->Rmeas, f->pass);
     }
-    hipLaunchKernelGGL(klt_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->klt_next_px, f->klt_status, N,
-                       cur.w[0], cur.h[0], f->cfg.kill_pad, fxc, fyc, cxc, cyc, r0, r1, cov_px, s0, s1, f->zmeas, f->Rmeas,
-                       f->pass);
     return EKFVIO_OK;
 }
 
 // Frame ingest without a host wait: the caller's image is copied into the handle's pinned staging buffer (so the
-// caller may reuse its buffer on return), then H2D, resize and pyramid are enqueued on the handle's stream.  The pinned
-// buffer is rewritten by the next frame, so the previous frame's H2D copy must have completed by then: the callers
-// below synchronise the stream before they return.
+// caller may reuse its buffer on return), then H2D, resize and pyramid are enqueued.  The pinned buffer is rewritten by
+// the next frame, so the previous frame's H2D copy must have completed by then: the callers below synchronise the
+// stream before they return.
+// (Measured and dropped: the upload and the pyramid on a stream of their own beside process(dt), joined by an event in
+// front of the tracker.  The two cross-stream waits cost more than the 12 us of overlap they buy: 161 instead of 141 us
+// per frame at N = 64.)
 static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                               const float K[9]) {
     if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
@@ -688,7 +936,8 @@ static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t wi
     } else {
         for (int y = 0; y < height; y++) memcpy(f->h_image + (size_t)y * width, image + (size_t)y * stride, width);
     }
-    HIPK(f, hipMemcpyAsync(f->staging, f->h_image, (size_t)width * height, hipMemcpyHostToDevice, f->stream));
+    hipStream_t st = f->stream;
+    HIPK(f, hipMemcpyAsync(f->staging, f->h_image, (size_t)width * height, hipMemcpyHostToDevice, st));
     f->cur ^= 1;  // the former current frame becomes the previous one (frame_buffer depth 2)
     KltFrame& fr = f->frames[f->cur];
     for (int i = 0; i < 9; i++) fr.K[i] = K[i];
@@ -697,9 +946,9 @@ static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t wi
         fr.K[2] = (float)((double)K[2] / s);
         fr.K[4] = (float)((double)K[4] / s);
         fr.K[5] = (float)((double)K[5] / s);
-        launch_frame_resize(f, width, height, s);
+        launch_frame_resize(f, width, height, s, st);
     }
-    build_pyramid(f, fr, s > 1 ? f->resized : f->staging, w, h);
+    build_pyramid(f, fr, s > 1 ? f->resized : f->staging, w, h, st);
     fr.valid = true;
     HIPK(f, hipGetLastError());
     return EKFVIO_OK;
@@ -815,6 +1064,21 @@ int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h
     if (deriv)
         HIPK(f, hipMemcpy2DAsync(deriv, (size_t)lw * 4, fr.deriv[level] + ((size_t)KLT_BORDER * pitch + KLT_BORDER) * 2,
                                  (size_t)pitch * 4, (size_t)lw * 4, lh, hipMemcpyDeviceToHost, f->stream));
+    HIPK(f, hipStreamSynchronize(f->stream));
+    return EKFVIO_OK;
+}
+
+int ekfvio_test_klt_padded_level(ekfvio_filter* f, int32_t level, int32_t* border, uint8_t* img, int16_t* deriv) {
+    if (!f || level < 0) return EKFVIO_EINVAL;
+    const KltFrame& fr = f->frames[f->cur];
+    if (!fr.valid || level >= fr.levels) return EKFVIO_ESTATE;
+    HIPK(f, hipSetDevice(f->device));
+    const int pw = fr.w[level] + 2 * KLT_BORDER, ph = fr.h[level] + 2 * KLT_BORDER, pitch = level_pitch(fr.w[level]);
+    if (border) *border = KLT_BORDER;
+    if (img) HIPK(f, hipMemcpy2DAsync(img, pw, fr.img[level], pitch, pw, ph, hipMemcpyDeviceToHost, f->stream));
+    if (deriv)
+        HIPK(f, hipMemcpy2DAsync(deriv, (size_t)pw * 4, fr.deriv[level], (size_t)pitch * 4, (size_t)pw * 4, ph, hipMemcpyDeviceToHost,
+                                 f->stream));
     HIPK(f, hipStreamSynchronize(f->stream));
     return EKFVIO_OK;
 }

@@ -297,6 +297,16 @@ class KLTTracker:
                                                     der.ctypes.data_as(C.POINTER(C.c_int16))))
         return img, der
 
+    def padded_level(self, l):
+        """Test hook: level l with its border, as the tracker reads it."""
+        w, h, b = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.ekf._chk(self.lib.ekfvio_klt_get_level(self.ekf.h, l, C.byref(w), C.byref(h), None, None))
+        self.ekf._chk(self.lib.ekfvio_test_klt_padded_level(self.ekf.h, l, C.byref(b), None, None))
+        img = np.zeros((h.value + 2 * b.value, w.value + 2 * b.value), np.uint8)
+        der = np.zeros((h.value + 2 * b.value, w.value + 2 * b.value, 2), np.int16)
+        self.ekf._chk(self.lib.ekfvio_test_klt_padded_level(self.ekf.h, l, C.byref(b), _u8(img), der.ctypes.data_as(C.POINTER(C.c_int16))))
+        return img, der, b.value
+
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))

@@ -167,6 +167,9 @@ int ekfvio_klt_uncertainty_points(ekfvio_filter* f, const float* ref_px, const f
 /* Test hook: interior of pyramid level `level` of the current frame (8-bit image, w*h, and
  * interleaved int16 Scharr dx,dy, w*h*2).  Either output may be NULL. */
 int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h, uint8_t* img, int16_t* deriv);
+/* Test hook: the same level WITH its border as the tracker reads it: (w + 2 border) x (h + 2 border) image bytes
+ * (reflect-101 border) and int16 pairs (zero border).  `border` (may be NULL) receives the border width (24). */
+int ekfvio_test_klt_padded_level(ekfvio_filter* f, int32_t level, int32_t* border, uint8_t* img, int16_t* deriv);
 
 /* EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) without the ROS
  * publishing: first frame only stores the image and stamp; later frames run

@@ -46,6 +46,29 @@ def test_pyramid_and_derivatives_bit_exact(crop):
     g.close()
 
 
+def test_padded_levels_hold_reflect101_borders_whatever_the_buffers_held_before():
+    """What the tracker reads: every level with a 24-pixel border, the image mirrored (BORDER_REFLECT_101, what OpenCV's
+    pyramid border holds), the derivatives zero.  A larger frame first, so the planes are dirty where the smaller frames'
+    borders (and, with the smaller pitch, everything else) come to lie; sizes that are no multiple of the 32-pixel tile,
+    and levels narrower than two borders (several reflections)."""
+    full = grey("640_480_test")
+    g = TightlyCoupledEKF(max_features=4)
+    t = KLTTracker(g)
+    for crop in [(480, 640), (251, 333), (97, 61), (120, 160), (23, 70), (480, 640)]:
+        img = full[:crop[0], :crop[1]].copy()
+        t.push_frame(img, K)
+        o = KltFrame(img)
+        for l in range(o.levels):
+            gi, gd, b = t.padded_level(l)
+            oi, od = o.level(l)
+            assert b == 24
+            assert np.array_equal(gi, np.pad(oi, b, mode="reflect")), (crop, l)
+            want = np.zeros_like(gd)
+            want[b:-b, b:-b] = od
+            assert np.array_equal(gd, want), (crop, l)
+    g.close()
+
+
 @pytest.mark.parametrize("second", ["640_480_moved_test", "640_480_shear_test", "640_480_test"])
 def test_tracked_points_bit_exact_and_flow(second):
     a, b = grey("640_480_test"), grey(second)
