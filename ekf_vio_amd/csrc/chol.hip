@@ -116,18 +116,18 @@ __device__ __forceinline__ void store_tile(const float* T, float* __restrict__ G
     }
 }
 // The sign mask of a block column is requested like the tiles: a VECTOR load (every lane the same address), so that it
-// retires under the same vmcnt wait as the tile loads issued behind it.  As a scalar load it sat on lgkmcnt with the LDS
-// traffic and its cold-L2 latency (the mask was written by the previous launch, on another compute unit) landed on the
-// chain: 2.3 us per filter step at N = 256 (same-box A/B, scripts/ab_lib.py).  sign_mask_request before the tile loads,
-// sign_mask_value after the barrier that follows them.
+// retires with the tile loads issued around it.  As a scalar load it sat on lgkmcnt with the LDS traffic and its cold-L2
+// latency (the mask was written by the previous launch, on another compute unit) landed on the chain: 2.3 us per filter
+// step at N = 256 (same-box A/B, scripts/ab_lib.py).  The address goes through a VGPR zero the compiler cannot see
+// through, which makes it an ordinary vector load whose wait the compiler places itself (an asm load would not be
+// tracked: under register pressure the compiler may copy its destination before the data has arrived).
+// sign_mask_request next to the tile loads, sign_mask_value (first use) after the barrier that follows them.
 __device__ __forceinline__ unsigned long long sign_mask_request(const unsigned long long* p) {
-    unsigned long long v;
-    const unsigned zero = 0u;
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(zero), "s"(p) : "memory");
-    return v;
+    unsigned z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return p[z];
 }
 __device__ __forceinline__ unsigned long long sign_mask_value(unsigned long long v) {
-    asm volatile("" : "+v"(v));  // every use stays behind the wait that precedes this point
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
@@ -257,6 +257,85 @@ __device__ __forceinline__ f32x4 mma16(const float* As, int a_si, int a_sq, cons
 // register v is fed straight back as the k-slice {4g+v} of the next product's A operand (the
 // B operand is read from LDS with the matching k permutation), so the dependent chain is
 // MFMA -> MFMA with no LDS round trip; all B operands are preloaded.
+// The substitution's B operands, read once into registers: binv = the four 16x16 inverse diagonal blocks, nl = the six
+// off-diagonal 16x16 blocks of -L.  Separate from the substitution itself so that a caller can fetch them, then re-use
+// L_kk's LDS tile for a row block before it solves (chol_step_la_kernel's near tiles).
+struct TriOps {
+    float binv[4][4];   // Inv_p(li, 4g+v)
+    float nl[6][4];     // -L(16t+li, 16p+4g+v), (p,t) pairs in the order (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
+};
+__device__ __forceinline__ void tri_solve_preload(TriOps& o, const float* Tl, const float* Tinv, int lane) {
+    const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) o.binv[p][v] = Tinv[p * 16 * ILD + (4 * g + v) * ILD + li];
+    {
+        int e = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int t = p + 1; t < 4; t++, e++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) o.nl[e][v] = -Tl[(16 * p + 4 * g + v) * PLD + 16 * t + li];
+    }
+}
+// pin every operand in a register here: otherwise the LDS reads are sunk next to their MFMA
+// and their latency lands on the dependent chain
+__device__ __forceinline__ void tri_solve_pin(TriOps& o) {
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) asm volatile("" : "+v"(o.binv[p][v]));
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) asm volatile("" : "+v"(o.nl[q][v]));
+}
+template <int NT>
+__device__ __forceinline__ void tri_solve_load_x(f32x4 (&x)[NT][4], float* const (&Txs)[NT], int wave, int lane) {
+    const int r0 = 16 * wave, li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) x[n][b][v] = Txs[n][(16 * b + 4 * g + v) * PLD + r0 + li];
+}
+// the dependent MFMA chain and the write-back
+template <int NT>
+__device__ __forceinline__ void tri_solve_run(f32x4 (&x)[NT][4], float* const (&Txs)[NT], const TriOps& o, int wave, int lane) {
+    const int r0 = 16 * wave, li = lane & 15, g = lane >> 4;
+    int e0 = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        f32x4 y[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) y[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the NT tiles are independent chains: interleaved they keep the MFMA pipe busy
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) y[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.binv[p][v], x[n][p][v], y[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; n++) x[n][p] = y[n];
+        int e = e0;
+#pragma unroll
+        for (int t = p + 1; t < 4; t++, e++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) x[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.nl[e][v], y[n][v], x[n][t], 0, 0, 0);
+        e0 = e;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Txs[n][(16 * b + 4 * g + v) * PLD + r0 + li] = x[n][b][v];
+}
+// (the same substitution in one piece: the sweep's hot kernels keep this form, whose schedule is the measured one)
 template <int NT>
 __device__ __forceinline__ void tri_solve_fwd_n(float* const (&Txs)[NT], const float* Tl, const float* Tinv, int wave, int lane,
                                                 long long* st = nullptr) {
@@ -828,8 +907,17 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
 #endif
     CSTAMP(7);
-    const f32x16 up = (neg == 0ull) ? mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane)
-                                    : mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg);
+    f32x16 up;
+    if (neg == 0ull) {
+        up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
+    } else {
+        // Rare path, a real call, which may save and restore registers around it: the requested target values must have
+        // landed first.  Only the wait: naming tgt here (a pin) would make it a merged value at the join below, and the
+        // copies that merge needs sit in front of the hot path's wait (measured: wrong targets once the memory system is
+        // busy with other streams, scripts/handles_stress.py).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        up = mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg);
+    }
     CSTAMP(6);
     if (chain) {
         // next diagonal tile: update into LDS and factor it now (look-ahead)
@@ -937,6 +1025,227 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
             Sij[(size_t)c * ldt + r] = tv[q] - up[q];
         }
+    }
+}
+
+// The split sweep's block step with the panel solve folded in (many tiles per step, mb >= EKF_SWEEP_SPLIT_MB).
+// The split sweep used to be two launches per block step: chol_panel_kernel(k) for the panel blocks L_ik, then the
+// tiles.  At N = 1024 the panel launch is a few dozen workgroups and 5 us of latency, 32 times per update, with the
+// chip idle.  Here launch l does
+//   near tiles  (i, l+1), every row block i below the diagonal and all extra rows: step l-1's update from the STORED
+//               panel blocks L_i,l-1, L_l+1,l-1, then step l's from panel blocks the tile solves itself (L_il = A_il
+//               L_ll^-T, stored for the next launch; A_il is final: column l was the near column of launch l-1);
+//               tile (l+1, l+1) is the chain: updated, factored, stored, as in chol_step_kernel;
+//   far tiles   (i, j), j >= l+2: step l-1's update from stored panel blocks: one step behind the near column.
+// Every tile still receives its updates in ascending step order, one subtraction per step: bit-identical to the
+// two-launch form.  Far tiles need no solve, near tiles fetch the solve's operands into registers and then re-use
+// L_ll's LDS tile for their second row block, so the kernel stays at two LDS tiles (four workgroups per compute unit).
+__global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
+                                                           float* __restrict__ Linv, int l, int mb, int rb, int idb0, int* info,
+                                                           unsigned long long* Lsign) {
+    __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];
+    __shared__ __attribute__((aligned(16))) float Tj[PB * PLD];
+    __shared__ float Tinv[INV_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int r = mb - 1 - l;       // block columns right of l
+    const int nnear = r + rb;       // column l+1: the chain, r-1 row blocks of A below it, the extra row blocks
+    int t = blockIdx.x, i, j;
+    const bool near = t < nnear;
+    if (near) {
+        j = l + 1;
+        i = (t < r) ? l + 1 + t : mb + (t - r);
+    } else {
+        t -= nnear;
+        const int rr = r - 1, ntri = rr * (rr + 1) / 2;
+        if (t < ntri) {
+            int ii = 0;
+            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+            i = l + 2 + ii;
+            j = l + 2 + (t - ii * (ii + 1) / 2);
+        } else {
+            t -= ntri;
+            i = mb + t / rr;
+            j = l + 2 + t % rr;
+        }
+    }
+    const int ic = i - idb0;                       // identity block row c: block (i,k) is zero for k < c
+    const bool has0 = l >= 1 && !(ic > l - 1);      // step l-1 reaches this row block
+    const bool has1 = near && !(ic > l);            // step l does
+    if (!has0 && !has1) return;
+    const bool chain = near && i == j;
+    unsigned long long neg0 = 0ull, neg1 = 0ull;
+    float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
+    const int rw = wr * 32 + (lane & 31);
+    f32x16 up0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) up0[q] = 0.f;
+
+    if (!near) {  // far tile: one stored-operand update, the plain tile of the two-launch sweep for step l-1
+        neg0 = sign_mask_request(Lsign + l - 1);
+        load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)i * PB, ldl, tid);
+        if (i != j) load_tile(Tj, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
+        __syncthreads();
+        neg0 = sign_mask_value(neg0);
+        const float* Bj = (i != j) ? Tj : Ti;
+        const f32x16 up = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg0);
+        float tv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            tv[q] = Sij[(size_t)c * lds + rw];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            Sij[(size_t)c * lds + rw] = tv[q] - up[q];
+        }
+        return;
+    }
+
+    if (!chain) {
+        // ---- near tile below the diagonal / extra row ----
+        if (has0) {
+            neg0 = sign_mask_request(Lsign + l - 1);
+            load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)i * PB, ldl, tid);
+            load_tile(Tj, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
+            __syncthreads();
+            neg0 = sign_mask_value(neg0);
+            up0 = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane, neg0);
+            __syncthreads();
+        }
+        // L_ll and its inverses -> the solve's operands in registers; then the two row blocks take the tiles' place
+        neg1 = sign_mask_request(Lsign + l);
+        load_tile(Tj, L + (size_t)l * PB * ldl + (size_t)l * PB, ldl, tid);
+        load_inv(Tinv, Linv + (size_t)l * PB * PB, tid);
+        __syncthreads();
+        neg1 = sign_mask_value(neg1);
+        TriOps ops;
+        tri_solve_preload(ops, Tj, Tinv, lane);
+        tri_solve_pin(ops);
+        __syncthreads();
+        load_tile(Ti, S + (size_t)l * PB * lds + (size_t)i * PB, lds, tid);
+        load_tile(Tj, S + (size_t)l * PB * lds + (size_t)j * PB, lds, tid);
+        __syncthreads();
+        {
+            float* const tt[2] = {Ti, Tj};
+            f32x4 x[2][4];
+            tri_solve_load_x<2>(x, tt, wave, lane);
+            tri_solve_run<2>(x, tt, ops, wave, lane);
+        }
+        __syncthreads();
+        store_tile(Ti, L + (size_t)l * PB * ldl + (size_t)i * PB, ldl, tid);  // unsigned: read back as an operand (sign_irows_kernel)
+        const f32x16 up1 = (neg1 == 0ull) ? mma64(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane, neg1);
+        float tv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            tv[q] = Sij[(size_t)c * lds + rw];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float a = has0 ? tv[q] - up0[q] : tv[q];
+            Sij[(size_t)c * lds + rw] = a - up1[q];
+        }
+        return;
+    }
+
+    // ---- the chain: tile (l+1, l+1) ----
+    // everything it reads from memory is requested at once: the stored block L_j,l-1 -> Ti, L_ll -> Tj (stays: i == j
+    // leaves the second row-block tile unused), and A_jl into registers, written to Ti once step l-1's product has read it
+    if (has0) neg0 = sign_mask_request(Lsign + l - 1);
+    neg1 = sign_mask_request(Lsign + l);
+    float4 areg[4];
+    {
+        const float* A = S + (size_t)l * PB * lds + (size_t)j * PB;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int e = tid + it * 256;
+            areg[it] = *reinterpret_cast<const float4*>(A + (size_t)(e >> 4) * lds + (e & 15) * 4);
+        }
+    }
+    if (has0) load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
+    load_tile(Tj, L + (size_t)l * PB * ldl + (size_t)l * PB, ldl, tid);
+    load_inv(Tinv, Linv + (size_t)l * PB * PB, tid);
+    __syncthreads();
+    if (has0) neg0 = sign_mask_value(neg0);
+    neg1 = sign_mask_value(neg1);
+    if (has0) {
+        up0 = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane, neg0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int e = tid + it * 256;
+        *reinterpret_cast<float4*>(Ti + (e >> 4) * PLD + (e & 15) * 4) = areg[it];
+    }
+    __syncthreads();
+    tri_solve_fwd(Ti, Tj, Tinv, wave, lane);  // L_jl = A_jl L_ll^-T
+    __syncthreads();
+    float tgt[16];
+    {   // target tile requested before the product, awaited behind it (see chol_step_kernel)
+        const unsigned off0 = ((unsigned)(wc * 32 + 4 * (lane >> 5)) * (unsigned)lds + (unsigned)rw) * 4u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const unsigned off = off0 + (unsigned)((q & 3) + 8 * (q >> 2)) * (unsigned)lds * 4u;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(tgt[q]) : "v"(off), "s"(Sij) : "memory");
+        }
+    }
+    f32x16 up1;
+    if (neg1 == 0ull) {
+        up1 = mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane);
+    } else {  // rare path, a real call: the requested target values must have landed first (see chol_step_kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        up1 = mma64_signed(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane, neg1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; q++) asm volatile("" : "+v"(tgt[q]));
+    float* Tl = Tj;  // every wavefront is past its substitution (barrier above): L_ll's tile takes the updated diagonal tile
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        const float a = has0 ? tgt[q] - up0[q] : tgt[q];
+        Tl[c * PLD + rw] = a - up1[q];
+    }
+    __syncthreads();
+    float* Ldst = L + (size_t)j * PB * ldl + (size_t)j * PB;
+    float* Idst = Linv + (size_t)(l + 1) * PB * PB;
+    float* Pdst = L + (size_t)l * PB * ldl + (size_t)j * PB;
+    const float* Tl_c = Tl;
+    const float* Ti_c = Ti;
+    const float* Tinv_c = Tinv;
+    auto idle = [&](auto pc, int wv) {  // stores under the pivot chain (see chol_step_kernel)
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p == 2) {
+            if (wv >= 2) store_cols<0, 32, 128, true>(Tl_c, Ldst, ldl, tid - 128);
+        } else if constexpr (p == 3) {
+            store_cols<32, 16, 192, true>(Tl_c, Ldst, ldl, tid - 64);
+            store_inv_blocks(Tinv_c, Idst, 0, tid - 64);
+            store_cols<0, 64, 192, false>(Ti_c, Pdst, ldl, tid - 64);
+        }
+    };
+    const bool bad = potrf64_lds<EKF_POTRF_FV>(Tl, Tinv, tid, nullptr, idle);
+    unsigned long long negn = 0ull;
+    if (bad) {  // workgroup-uniform, rare: the updated tile is formed again and factored as U S U^T
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float a = has0 ? Sij[(size_t)c * lds + rw] - up0[q] : Sij[(size_t)c * lds + rw];
+            Tl[c * PLD + rw] = a - up1[q];
+        }
+        negn = potrf64_signed(Tl, Tinv, tid);
+        store_tile_lower(Tl, Ldst, ldl, tid);
+        store_inv(Tinv, Idst, tid);
+    } else {
+        store_cols<48, 16, 256, true>(Tl_c, Ldst, ldl, tid);
+        if (tid < 64) store_inv_blocks(Tinv_c, Idst, 3, tid);
+    }
+    if (tid == 0) {
+        Lsign[l + 1] = negn;
+        if (bad) atomicOr(info, 1);
     }
 }
 
@@ -1302,6 +1611,20 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
             hipLaunchKernelGGL((chol_step_kernel<true, true>), grid, dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, k, mb, idb0,
                                f->info, f->Lsign, f->sweep_dbg, sc);
         }
+        return;
+    }
+    // EKFVIO_SWEEP_LA=0 (diagnostic): the two-launch split sweep (panel launch + tile launch per block step)
+    static const bool la_env = getenv("EKFVIO_SWEEP_LA") ? atoi(getenv("EKFVIO_SWEEP_LA")) != 0 : true;
+    if (split && la_env) {
+        for (int l = 0; l + 1 < mb; l++) {
+            const int r = mb - 1 - l;
+            const int far = l >= 1 ? (r - 1) * r / 2 + rb * (r - 1) : 0;
+            hipLaunchKernelGGL(chol_step_la_kernel, dim3(r + rb + far), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, l, mb, rb,
+                               idb0, f->info, f->Lsign);
+        }
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0, f->Lsign, 0);
+        hipLaunchKernelGGL(sign_irows_kernel, dim3((m_pad + 255) / 256, mb), dim3(256), 0, f->stream, Laug, ld, idb0 * PB, m_pad,
+                           f->Lsign);
         return;
     }
     for (int k = 0; k + 1 < mb; k++) {

@@ -922,14 +922,21 @@ int klt_track_device(ekfvio_filter* f) {
 // (Measured and dropped: the upload and the pyramid on a stream of their own beside process(dt), joined by an event in
 // front of the tracker.  The two cross-stream waits cost more than the 12 us of overlap they buy: 161 instead of 141 us
 // per frame at N = 64.)
-static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
-                              const float K[9]) {
+static int push_frame_check(const ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                            const float K[9]) {
     if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
     if (width > f->cfg.max_image_width || height > f->cfg.max_image_height) return EKFVIO_ECAPACITY;
+    const int s = f->cfg.inverse_image_scale > 1 ? f->cfg.inverse_image_scale : 1;
+    if (width / s < 1 || height / s < 1) return EKFVIO_EINVAL;
+    return EKFVIO_OK;
+}
+static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                              const float K[9]) {
+    const int rcc = push_frame_check(f, image, width, height, stride, K);
+    if (rcc != EKFVIO_OK) return rcc;
     // Frame::Frame (Frame.cpp:15-42): cv::resize to (cols / s, rows / s), K(0,0), K(0,2), K(1,1), K(1,2) divided by s
     const int s = f->cfg.inverse_image_scale > 1 ? f->cfg.inverse_image_scale : 1;
     const int w = width / s, h = height / s;
-    if (w < 1 || h < 1) return EKFVIO_EINVAL;
     HIPK(f, hipSetDevice(f->device));
     if (stride == width) {
         memcpy(f->h_image, image, (size_t)width * height);
@@ -1091,9 +1098,17 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
     if (!f) return EKFVIO_EINVAL;
     const bool first = !f->frames[f->cur].valid;
     if (!first && f->have_stamp && !(stamp - f->t_stamp >= 0)) return EKFVIO_EINVAL;  // ROS_ASSERT(dt >= 0)
-    // nothing below waits for the device until the status word is read at the very end: the frame upload, the
-    // pyramid, process(dt), the tracker and the update are enqueued back to back
-    int rc = push_frame_enqueue(f, image, width, height, stride, K);
+    // nothing below waits for the device until the status word is read at the very end: process(dt), the frame
+    // upload, the pyramid, the tracker and the update are enqueued back to back.  process(dt) goes first: it does not
+    // depend on the image, so the device runs it while the host copies the frame into the pinned buffer.
+    int rc = push_frame_check(f, image, width, height, stride, K);
+    if (rc != EKFVIO_OK) return rc;
+    const float dt = first ? 0.f : (float)(stamp - f->t_stamp);
+    if (!first) {
+        HIPK(f, hipSetDevice(f->device));
+        launch_predict(f, dt);
+    }
+    rc = push_frame_enqueue(f, image, width, height, stride, K);
     if (rc != EKFVIO_OK) return rc;
     if (first) {
         // first frame: remember the stamp (tc_ekf.t = f.t) and return; the caller replenishes
@@ -1105,8 +1120,6 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         HIPK(f, hipStreamSynchronize(f->stream));
         return EKFVIO_OK;
     }
-    const float dt = (float)(stamp - f->t_stamp);
-    launch_predict(f, dt);
     f->t_stamp = stamp;
     f->have_stamp = true;
     int status = EKFVIO_OK;
