@@ -210,7 +210,8 @@ __device__ __forceinline__ f32x16 mma64(const float* As, int a_si, int a_sq, con
     const int li = lane & 31, lk = lane >> 5;
     const float* ap = As + (wr * 32 + li) * a_si + lk * a_sq;
     const float* bp = Bs + (wc * 32 + li) * b_sj + lk * b_sq;
-#pragma unroll 8
+    // completely unrolled: no loop, so loads a caller has in flight stay in flight across the product (chol_step_kernel)
+#pragma unroll
     for (int q = 0; q < PB; q += 2) {
         const float a = ap[q * a_sq];
         const float b = bp[q * b_sq];
@@ -888,12 +889,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
         ldt = sc.ldk;
     }
     const int r = wr * 32 + (lane & 31);
-#ifndef EKF_CHOL_LATE_TARGET
-    // The chain workgroup requests its target tile BEFORE the 64^3 product and waits for it AFTER: the memory round
-    // trip runs under the MFMA stream.  The compiler cannot express that (it waits for a load before the first use it
-    // can see, and a register pin is such a use), so the loads are inline asm, which its s_waitcnt insertion does not
-    // track, and the wait is written by hand.  (Its own vmcnt waits stay correct: the counter retires in order, extra
-    // outstanding loads only make them wait longer.)
+    // The chain workgroup requests its target tile BEFORE the 64^3 product and uses it AFTER: the memory round trip runs
+    // under the MFMA stream.  Plain loads: the compiler keeps their wait in front of the first use as long as nothing
+    // between forces it earlier -- a loop does (it waits for every outstanding load before entering one), which is why
+    // mma64 is unrolled completely.  (An earlier form issued the loads from inline asm and placed the wait by hand;
+    // the compiler does not know such a register is still in flight and may copy it: scripts/handles_stress.py.)
     float tgt[16];
     if (chain) {
         // scalar base + 32-bit lane offset + a scalar step per element: one VALU add per load instead of a 64-bit
@@ -902,38 +902,23 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const unsigned off = off0 + (unsigned)((q & 3) + 8 * (q >> 2)) * (unsigned)lds * 4u;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(tgt[q]) : "v"(off), "s"(Sij) : "memory");
+            tgt[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Sij) + off);
         }
     }
-#endif
     CSTAMP(7);
     f32x16 up;
     if (neg == 0ull) {
         up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
     } else {
-        // Rare path, a real call, which may save and restore registers around it: the requested target values must have
-        // landed first.  Only the wait: naming tgt here (a pin) would make it a merged value at the join below, and the
-        // copies that merge needs sit in front of the hot path's wait (measured: wrong targets once the memory system is
-        // busy with other streams, scripts/handles_stress.py).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         up = mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg);
     }
     CSTAMP(6);
     if (chain) {
         // next diagonal tile: update into LDS and factor it now (look-ahead)
-#ifndef EKF_CHOL_LATE_TARGET
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 16; q++) asm volatile("" : "+v"(tgt[q]));  // uses stay behind the wait
-#endif
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-#ifndef EKF_CHOL_LATE_TARGET
             Tl[c * PLD + r] = tgt[q] - up[q];
-#else
-            Tl[c * PLD + r] = Sij[(size_t)c * lds + r] - up[q];
-#endif
         }
         __syncthreads();
         CSTAMP(3);
@@ -1184,24 +1169,15 @@ __global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict_
     tri_solve_fwd(Ti, Tj, Tinv, wave, lane);  // L_jl = A_jl L_ll^-T
     __syncthreads();
     float tgt[16];
-    {   // target tile requested before the product, awaited behind it (see chol_step_kernel)
+    {   // target tile requested before the product, used behind it (see chol_step_kernel)
         const unsigned off0 = ((unsigned)(wc * 32 + 4 * (lane >> 5)) * (unsigned)lds + (unsigned)rw) * 4u;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const unsigned off = off0 + (unsigned)((q & 3) + 8 * (q >> 2)) * (unsigned)lds * 4u;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(tgt[q]) : "v"(off), "s"(Sij) : "memory");
+            tgt[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Sij) + off);
         }
     }
-    f32x16 up1;
-    if (neg1 == 0ull) {
-        up1 = mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane);
-    } else {  // rare path, a real call: the requested target values must have landed first (see chol_step_kernel)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        up1 = mma64_signed(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane, neg1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 16; q++) asm volatile("" : "+v"(tgt[q]));
+    const f32x16 up1 = (neg1 == 0ull) ? mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane, neg1);
     float* Tl = Tj;  // every wavefront is past its substitution (barrier above): L_ll's tile takes the updated diagonal tile
 #pragma unroll
     for (int q = 0; q < 16; q++) {
