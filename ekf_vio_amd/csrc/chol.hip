@@ -1073,13 +1073,13 @@ __global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict_
         __syncthreads();
         neg0 = sign_mask_value(neg0);
         const float* Bj = (i != j) ? Tj : Ti;
-        const f32x16 up = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg0);
-        float tv[16];
+        float tv[16];  // the target tile's round trip runs under the product
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
             tv[q] = Sij[(size_t)c * lds + rw];
         }
+        const f32x16 up = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg0);
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -1120,13 +1120,13 @@ __global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict_
         }
         __syncthreads();
         store_tile(Ti, L + (size_t)l * PB * ldl + (size_t)i * PB, ldl, tid);  // unsigned: read back as an operand (sign_irows_kernel)
-        const f32x16 up1 = (neg1 == 0ull) ? mma64(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane, neg1);
         float tv[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
             tv[q] = Sij[(size_t)c * lds + rw];
         }
+        const f32x16 up1 = (neg1 == 0ull) ? mma64(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane, neg1);
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);

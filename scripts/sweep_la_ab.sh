@@ -1,4 +1,4 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_shapes.py tests/test_gpu_parity.py -x -q -m gpu -k "1024 or cholesky or indefinite or sweep or solve" > gpurun_out/pytest_la.log 2>&1; tail -4 gpurun_out/pytest_la.log
+# N = 1024 bench under the two forms of the split sweep (EKFVIO_SWEEP_LA=0: panel launch + tile launch per block step)
 for LA in 0 1; do
 EKFVIO_SWEEP_LA=$LA timeout -k 10 400 python bench.py --landmarks 1024 --steps 40 --warmup 5 --no-cpu-baseline --no-full-loop > gpurun_out/bench_la_$LA.json 2> gpurun_out/bench_la_$LA.err
 python3 -c "
