@@ -201,8 +201,8 @@ def full_loop(n_landmarks, device, frames=40, warm=6):
                     "pyramid_bytes": pyr_bytes,
                     "pyramid_gb_per_s": (pyr_bytes / (pyr_us * 1e-6) / 1e9) if pyr_us else None,
                     "pyramid_frac_of_hbm_peak": (pyr_bytes / (pyr_us * 1e-6) / 1e9 / PEAK_HBM_GBS) if pyr_us else None,
-                    "note": "event-bracketed stage times (include ~5 us of launch gaps per stage); the pyramid is 4 launches over 0.4 MB in / 2.1 MB out: latency bound, "
-                            "not HBM bound; the tracker is one wavefront per landmark, latency bound on its Gauss-Newton chain"}}
+                    "note": "event-bracketed stage times (include ~5 us of launch gaps per stage); the pyramid is one launch over 0.3 MB in / 2.6 MB out whose duration is a workgroup's "
+                            "latency, not HBM bound; the tracker is one wavefront per landmark, latency bound on its Gauss-Newton chain"}}
 
 
 def klt_cpu_baseline(n_points):
