@@ -19,5 +19,3 @@ print("sweep launch durations (us), last update:", " ".join("%.1f" % ((int(r["En
 print("gaps to next launch (us):", " ".join("%.1f" % ((int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3) for a, b in zip(last[:-1], last[1:])))
 print("sweep span (us): %.1f" % ((int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])) / 1e3))
 PY
-tail -1 $R/gpurun_out/np_$TAG.log | python3 -c "
-import json,sys; r=json.loads(sys.stdin.read()); print(r['value'], r['ms_per_step'])"
