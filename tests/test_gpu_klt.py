@@ -89,6 +89,26 @@ def test_tracked_points_bit_exact_and_flow(second):
     g.close()
 
 
+@pytest.mark.parametrize("win,levels,iters", [(3, 3, 30), (7, 3, 30), (15, 2, 8), (19, 1, 30), (21, 0, 3)])
+def test_other_windows_levels_and_iteration_budgets_bit_exact(win, levels, iters):
+    """The tracker's lane geometry is three lanes per window row with runs of ceil(win / 3) pixels: every odd window up to
+    the reference's 21 (Params.h) must give the oracle's positions and status, with fewer pyramid levels and a smaller
+    iteration budget as well."""
+    a, b = grey("640_480_test"), grey("640_480_moved_test")
+    g = TightlyCoupledEKF(max_features=256, klt_window_size=win, klt_max_pyramid_level=levels, klt_max_iterations=iters)
+    t = KLTTracker(g)
+    t.push_frame(a, K), t.push_frame(b, K)
+    pts = np.vstack([grid_points(10), [[5.0, 5.0], [-40.0, 100.0], [639.0, 479.0], [320.5, 0.25], [2.0, 470.0]]]).astype(np.float32)
+    guess = (pts + np.array([-20.0, -6.0], np.float32)).astype(np.float32)  # a coarse prediction, as the filter would give
+    A, B = KltFrame(a, win=win, max_level=levels), KltFrame(b, win=win, max_level=levels)
+    on, os_, _ = klt_track(A, B, pts, guess.copy(), win=win, max_iter=iters)
+    gn, gs = t.track_points(pts, guess.copy())
+    assert np.array_equal(gs, os_)
+    assert np.array_equal(gn, on), float(np.abs(gn - on).max())
+    assert gs.sum() >= 60
+    g.close()
+
+
 def test_small_image_reduces_levels_and_flat_patch_fails():
     img = grey("640_480_test")[::4, ::4].copy()  # 160x120: level 3 would be 20x15 <= window
     g = TightlyCoupledEKF(max_features=8)
