@@ -112,7 +112,9 @@ struct ekfvio_filter {
     float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
     float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
     int* info = nullptr;       // [4] device words: [0] non-positive pivot seen, [1] frame counter of uploaded sequences, [2] device-side m
-    int* h_info = nullptr;     // pinned host mirror
+    int* h_info = nullptr;     // pinned, device-mapped: [0] status word, [1] sequence number (publish_status_kernel)
+    int* d_hinfo = nullptr;    // the device's address of h_info
+    int status_seq = 0;
     unsigned char* h_meas = nullptr;  // pinned staging for one frame's (z, R, pass): one H2D copy per ekfvio_update
     unsigned char* d_meas = nullptr;  // its device image: z at 0, R at 8N_cap, pass at 24N_cap bytes
     // uploaded measurement sequences
@@ -240,6 +242,8 @@ void launch_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[
 int fast_alloc(ekfvio_filter* f);
 void fast_free(ekfvio_filter* f);
 void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale, hipStream_t st);
+// Waits for everything on the handle's stream and returns the factorisation's status word through *status (api.hip).
+int wait_status(ekfvio_filter* f, int* status);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
 int add_features_device(ekfvio_filter* f, int k);
 // The two P-update GEMM launches of an update with m measurement rows, `reps` times, into scratch (P2, Gm): the

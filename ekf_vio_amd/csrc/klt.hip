@@ -1136,9 +1136,10 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         if (rc != EKFVIO_OK) return rc;
     }
     // the frame's single host wait: status word of the factorisation
-    HIPK(f, hipMemcpyAsync(f->h_info, f->info, sizeof(int), hipMemcpyDeviceToHost, f->stream));
-    HIPK(f, hipStreamSynchronize(f->stream));
-    if (f->h_info[0]) {
+    int bad = 0;
+    rc = wait_status(f, &bad);
+    if (rc != EKFVIO_OK) return rc;
+    if (bad) {
         status = EKFVIO_ENUMERIC;
         HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
     }
