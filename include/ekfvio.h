@@ -177,7 +177,9 @@ int ekfvio_test_klt_padded_level(ekfvio_filter* f, int32_t level, int32_t* borde
  * two replenishFeatures calls of addFrame (:154, :172) run on the device as well; with 0 the
  * caller adds landmarks (ekfvio_replenish, or its own detector + ekfvio_add_features).
  * The image is copied before the call returns; the call waits for the device once, at its end
- * (status word), the pass flags of the tracker never travel to the host.
+ * (status word), the pass flags of the tracker never travel to the host.  That wait (here, in ekfvio_update and in
+ * ekfvio_synchronize) polls a word the device writes into pinned host memory for up to 300 us of the calling
+ * thread's time, then blocks in hipStreamSynchronize.
  * Returns EKFVIO_OK or EKFVIO_ENUMERIC. */
 int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height,
                       int32_t stride, const float K[9]);
