@@ -1021,7 +1021,10 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
 //               panel blocks L_i,l-1, L_l+1,l-1, then step l's from panel blocks the tile solves itself (L_il = A_il
 //               L_ll^-T, stored for the next launch; A_il is final: column l was the near column of launch l-1);
 //               tile (l+1, l+1) is the chain: updated, factored, stored, as in chol_step_kernel;
-//   far tiles   (i, j), j >= l+2: step l-1's update from stored panel blocks: one step behind the near column.
+//   far tiles   (i, j), j = l+2, l+4, ...: steps l-2 AND l-1 from stored panel blocks.  A column is visited every second
+//               launch and takes two steps per visit, so the trailing matrix -- whose read-modify-write out of Infinity
+//               Cache is what bounds these launches -- is read and written half as often for the same arithmetic.  Column
+//               j's last far visit is launch j-2 (steps j-4, j-3); launch j-1 is its near visit (steps j-2, j-1).
 // Every tile still receives its updates in ascending step order, one subtraction per step: bit-identical to the
 // two-launch form.  Far tiles need no solve, near tiles fetch the solve's operands into registers and then re-use
 // L_ll's LDS tile for their second row block, so the kernel stays at two LDS tiles (four workgroups per compute unit).
@@ -1042,17 +1045,12 @@ __global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict_
         i = (t < r) ? l + 1 + t : mb + (t - r);
     } else {
         t -= nnear;
-        const int rr = r - 1, ntri = rr * (rr + 1) / 2;
-        if (t < ntri) {
-            int ii = 0;
-            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-            i = l + 2 + ii;
-            j = l + 2 + (t - ii * (ii + 1) / 2);
-        } else {
-            t -= ntri;
-            i = mb + t / rr;
-            j = l + 2 + t % rr;
+        j = l + 2;  // columns l+2, l+4, ...: mb - j row blocks of A from the diagonal down, then the extra rows
+        while (t >= mb - j + rb) {
+            t -= mb - j + rb;
+            j += 2;
         }
+        i = (t < mb - j) ? j + t : mb + (t - (mb - j));
     }
     const int ic = i - idb0;                       // identity block row c: block (i,k) is zero for k < c
     const bool has0 = l >= 1 && !(ic > l - 1);      // step l-1 reaches this row block
@@ -1066,7 +1064,21 @@ __global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict_
 #pragma unroll
     for (int q = 0; q < 16; q++) up0[q] = 0.f;
 
-    if (!near) {  // far tile: one stored-operand update, the plain tile of the two-launch sweep for step l-1
+    if (!near) {  // far tile: steps l-2 (if it reaches this row block) and l-1 from stored panel blocks
+        const bool hasa = l >= 2 && !(ic > l - 2);
+        f32x16 upa;
+#pragma unroll
+        for (int q = 0; q < 16; q++) upa[q] = 0.f;
+        if (hasa) {
+            unsigned long long nega = sign_mask_request(Lsign + l - 2);
+            load_tile(Ti, L + (size_t)(l - 2) * PB * ldl + (size_t)i * PB, ldl, tid);
+            if (i != j) load_tile(Tj, L + (size_t)(l - 2) * PB * ldl + (size_t)j * PB, ldl, tid);
+            __syncthreads();
+            nega = sign_mask_value(nega);
+            const float* Ba = (i != j) ? Tj : Ti;
+            upa = (nega == 0ull) ? mma64(Ti, 1, PLD, Ba, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Ba, 1, PLD, wr, wc, lane, nega);
+            __syncthreads();
+        }
         neg0 = sign_mask_request(Lsign + l - 1);
         load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)i * PB, ldl, tid);
         if (i != j) load_tile(Tj, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
@@ -1083,7 +1095,8 @@ __global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict_
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            Sij[(size_t)c * lds + rw] = tv[q] - up[q];
+            const float a = hasa ? tv[q] - upa[q] : tv[q];
+            Sij[(size_t)c * lds + rw] = a - up[q];
         }
         return;
     }
@@ -1594,7 +1607,9 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     if (split && la_env) {
         for (int l = 0; l + 1 < mb; l++) {
             const int r = mb - 1 - l;
-            const int far = l >= 1 ? (r - 1) * r / 2 + rb * (r - 1) : 0;
+            int far = 0;  // columns l+2, l+4, ... from the diagonal down plus the extra rows
+            if (l >= 1)
+                for (int j = l + 2; j < mb; j += 2) far += mb - j + rb;
             hipLaunchKernelGGL(chol_step_la_kernel, dim3(r + rb + far), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, l, mb, rb,
                                idb0, f->info, f->Lsign);
         }
