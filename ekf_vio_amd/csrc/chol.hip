@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
             store_inv_blocks(Tinv_c, Linv, 0, tid - 64);
         }
     };
-    const bool bad = potrf64_lds<EKF_POTRF_FV>(A, Tinv, tid, nullptr, idle);
+    const bool bad = potrf64_lds<EKF_POTRF_FV>(A, Tinv, tid, dbg ? dbg + 800 : nullptr, idle);
     unsigned long long neg = 0ull;
     if (bad) {  // workgroup-uniform, rare: the tile is gathered again (its loads were consumed) and factored as U S U^T
         __syncthreads();

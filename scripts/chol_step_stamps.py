@@ -30,3 +30,8 @@ for k in range((2 * N + 63) // 64 - 1):
 if v[1000]:
     print("gather+potrf launch, chain workgroup: tile gather %d  factorisation %d  stores %d cycles; last gather workgroup ended %+d, first %+d cycles after the chain workgroup started"
           % (v[1001] - v[1000], v[1002] - v[1001], v[1003] - v[1002], v[1004] - v[1000], v[1005] - v[1000]))
+
+p = v[800:880]
+if p[1]:
+    print("  first tile's factorisation by panel (cycles): factor phases %s  trails %s  total %d"
+          % ([p[2 + 2 * q] - p[1 + 2 * q] for q in range(4)], [p[3 + 2 * q] - p[2 + 2 * q] for q in range(3)], p[10] - p[1]))
