@@ -137,7 +137,6 @@ struct ekfvio_filter {
     uint8_t* staging = nullptr;    // device staging for the uploaded image
     uint8_t* h_image = nullptr;    // pinned host staging: the caller's frame is copied here, so its buffer is free on return without a stream sync
     // --- frame ingest + replenishment (fast.hip) ---
-    uint8_t* resized = nullptr;    // Frame::Frame's cv::resize output (max image size)
     uint8_t* blurred = nullptr;    // replenishFeatures' cv::GaussianBlur output (only with cfg.fast_blur_sigma != 0)
     short* fast_score = nullptr;   // FAST score map of level 0 (-1 = no corner)
     int* fast_kp_xy = nullptr;     // keypoints in raster order
@@ -241,7 +240,6 @@ void launch_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[
 // fast.hip
 int fast_alloc(ekfvio_filter* f);
 void fast_free(ekfvio_filter* f);
-void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale, hipStream_t st);
 // Waits for everything on the handle's stream and returns the factorisation's status word through *status (api.hip).
 int wait_status(ekfvio_filter* f, int* status);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device

@@ -8,7 +8,7 @@
 // The arithmetic is OpenCV 3.x's (resize.cpp 8-bit INTER_LINEAR, fast.cpp / fast_score.cpp TYPE_9_16,
 // drawing.cpp Circle): everything is integer, so the kernels are bit-exact against oracle/fast_oracle.cpp.
 //
-// Mapping: resize and the FAST segment test + score are one thread per pixel (the 16 ring pixels become two
+// Mapping: the FAST segment test + score are one thread per pixel (the 16 ring pixels become two
 // 16-bit masks, "9 contiguous" is four shift-ands on the doubled mask).  Non-maximum suppression and the
 // raster-order compaction are three small launches (keypoints per row, scan over the rows, ordered write with
 // ballot prefixes inside a row), which keeps cv::FAST's keypoint order without a sort.  The first-fit selection is inherently sequential in
@@ -27,33 +27,6 @@
     } while (0)
 
 namespace {
-
-__device__ inline short sat_short_rn(float v) {
-    const int i = __float2int_rn(v);  // round half to even = cvRound
-    return (short)min(32767, max(-32768, i));
-}
-
-// cv::resize 8u INTER_LINEAR (resize.cpp): one thread per destination pixel
-__global__ void frame_resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int sstride, uint8_t* __restrict__ dst,
-                                    int dw, int dh, double scale_x, double scale_y) {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw) return;
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= sx;
-    if (sx < 0) { fx = 0; sx = 0; }
-    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    const int sy = (int)floorf(fy);
-    fy -= sy;
-    const int a0 = sat_short_rn((1.f - fx) * 2048), a1 = sat_short_rn(fx * 2048);
-    const int b0 = sat_short_rn((1.f - fy) * 2048), b1 = sat_short_rn(fy * 2048);
-    const int sx1 = min(sx + 1, sw - 1);
-    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-    const uint8_t *S0 = src + (size_t)sy0 * sstride, *S1 = src + (size_t)sy1 * sstride;
-    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
-    dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
-}
 
 // FAST-9/16 segment test + cornerScore<16>; score map: -1 = no corner.  img points at pixel (0,0) of a pitched image.
 __global__ void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h, int pitch, int threshold, short* __restrict__ score) {
@@ -384,7 +357,6 @@ static void gauss5_taps(float sigma, int k[5]) {
 int fast_alloc(ekfvio_filter* f) {
     const ekfvio_config& c = f->cfg;
     const size_t px = (size_t)c.max_image_width * c.max_image_height;
-    HIPF(f, hipMalloc((void**)&f->resized, px));
     if (c.fast_blur_sigma != 0.f) HIPF(f, hipMalloc((void**)&f->blurred, px));
     HIPF(f, hipMalloc((void**)&f->fast_score, px * sizeof(short)));
     f->fast_kp_cap = (int)(px / 4 + 1);
@@ -400,16 +372,9 @@ int fast_alloc(ekfvio_filter* f) {
 }
 
 void fast_free(ekfvio_filter* f) {
-    void* ptrs[] = {f->resized, f->blurred, f->fast_score, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt, f->fast_row_off};
+    void* ptrs[] = {f->blurred, f->fast_score, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt, f->fast_row_off};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-}
-
-// Frame::Frame's cv::resize: f->staging (w x h, tightly packed) -> f->resized ((w/s) x (h/s))
-void launch_frame_resize(ekfvio_filter* f, int w, int h, int inv_scale, hipStream_t st) {
-    const int dw = w / inv_scale, dh = h / inv_scale;
-    hipLaunchKernelGGL(frame_resize_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, st, f->staging, w, h, w, f->resized, dw,
-                       dh, (double)w / dw, (double)h / dh);
 }
 
 // cv::FAST on level 0 of the current frame -> f->fast_kp_* (raster order), count in f->fast_counts[0]

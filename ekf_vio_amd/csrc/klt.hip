@@ -92,6 +92,36 @@ struct PyrGeom {
     static constexpr int T = PYR_T >> L;                                         // owned tile edge
     static constexpr int S = T + 2 * H;                                          // region edge: 76, 36, 16, 6
 };
+// Frame::Frame's cv::resize(img, 1 / inverse_image_scale) (Frame.cpp:15-42), OpenCV 3.x resize.cpp 8-bit INTER_LINEAR: 11-bit
+// fixed-point weights (cvRound, saturated to short), horizontal pass kept at 16 fractional bits less 4, vertical pass with
+// the two-stage rounding of its VResizeLinear.  Destination pixel (dx, dy) of the (sw x sh) source.  The pyramid kernel
+// forms level 0 with this on the fly (a resize launch of its own used to write the resized frame first).
+struct ResizeArgs {
+    int on = 0, sw = 0, sh = 0;
+    double scale_x = 1.0, scale_y = 1.0;
+};
+__device__ inline short sat_short_rn(float v) {
+    const int i = __float2int_rn(v);  // round half to even = cvRound
+    return (short)min(32767, max(-32768, i));
+}
+__device__ inline uint8_t resize_pixel(const uint8_t* __restrict__ src, int sstride, const ResizeArgs& ra, int dx, int dy) {
+    float fx = (float)((dx + 0.5) * ra.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= ra.sw - 1) { fx = 0; sx = ra.sw - 1; }
+    float fy = (float)((dy + 0.5) * ra.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    const int a0 = sat_short_rn((1.f - fx) * 2048), a1 = sat_short_rn(fx * 2048);
+    const int b0 = sat_short_rn((1.f - fy) * 2048), b1 = sat_short_rn(fy * 2048);
+    const int sx1 = min(sx + 1, ra.sw - 1);
+    const int sy0 = min(max(sy, 0), ra.sh - 1), sy1 = min(max(sy + 1, 0), ra.sh - 1);
+    const uint8_t *S0 = src + (size_t)sy0 * sstride, *S1 = src + (size_t)sy1 * sstride;
+    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
+    return (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
 // calls fn(X) for every X in [-KLT_BORDER, w + KLT_BORDER) other than x itself whose reflect-101 image is x (0 <= x < w)
 template <class F>
 __device__ __forceinline__ void for_mirror_images(int x, int w, F&& fn) {
@@ -231,7 +261,8 @@ __device__ __forceinline__ void pyr_down_level(const uint8_t* Rs, uint8_t* Rd, c
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __restrict__ src, int spitch, PyrOut o, long long* dbg) {
+__global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __restrict__ src, int spitch, PyrOut o, long long* dbg,
+                                                             ResizeArgs ra) {
     // diagnostic phase stamps of one interior workgroup (scripts/klt_timing.py); dbg is null in production
 #define PSTAMP(slot)                                                                                                     \
     do {                                                                                                                 \
@@ -254,7 +285,12 @@ __global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __re
         // on either side, then a clamp for the region entries nothing reads (the region is 76 wide wherever the image
         // ends).  Smaller frames take the general reflection, rolled.
         constexpr int NL = (G::S * G::S + PYR_NT - 1) / PYR_NT;
-        if (w >= G::S && h >= G::S) {
+        if (ra.on) {
+            // level 0 is the resized frame: every region entry is resized out of the full-size source on the fly
+#pragma unroll 1
+            for (int e = tid; e < G::S * G::S; e += PYR_NT)
+                R0[e] = resize_pixel(src, spitch, ra, reflect101(ox + e % G::S, w), reflect101(oy + e / G::S, h));
+        } else if (w >= G::S && h >= G::S) {
             uint8_t v[NL];
 #pragma unroll
             for (int it = 0; it < NL; it++) {
@@ -817,7 +853,8 @@ void klt_free(ekfvio_filter* f) {
 }
 
 // Device-side part of klt_push_frame: staging -> pyramid + derivatives of frames[cur]
-static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int w, int h, hipStream_t st) {
+// src: the uploaded frame (sw x sh, tightly packed); the pyramid's level 0 is w x h = (sw / s) x (sh / s)
+static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int sw, int sh, int w, int h, hipStream_t st) {
     const int win = f->cfg.klt_window_size;
     fr.w[0] = w;
     fr.h[0] = h;
@@ -839,7 +876,15 @@ static int build_pyramid(ekfvio_filter* f, KltFrame& fr, const uint8_t* src, int
         o.h[l] = (l < fr.levels) ? fr.h[l] : 0;
         o.pitch[l] = (l < fr.levels) ? level_pitch(fr.w[l]) : 0;
     }
-    hipLaunchKernelGGL(klt_pyramid_kernel, dim3((w + PYR_T - 1) / PYR_T, (h + PYR_T - 1) / PYR_T), dim3(PYR_NT), 0, st, src, w, o, f->sweep_dbg);
+    ResizeArgs ra;  // Frame::Frame (Frame.cpp:15-42): level 0 = cv::resize(frame, (cols / s, rows / s))
+    if (w != sw || h != sh) {
+        ra.on = 1;
+        ra.sw = sw;
+        ra.sh = sh;
+        ra.scale_x = (double)sw / w;
+        ra.scale_y = (double)sh / h;
+    }
+    hipLaunchKernelGGL(klt_pyramid_kernel, dim3((w + PYR_T - 1) / PYR_T, (h + PYR_T - 1) / PYR_T), dim3(PYR_NT), 0, st, src, sw, o, f->sweep_dbg, ra);
     return EKFVIO_OK;
 }
 
@@ -953,9 +998,8 @@ static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t wi
         fr.K[2] = (float)((double)K[2] / s);
         fr.K[4] = (float)((double)K[4] / s);
         fr.K[5] = (float)((double)K[5] / s);
-        launch_frame_resize(f, width, height, s, st);
     }
-    build_pyramid(f, fr, s > 1 ? f->resized : f->staging, w, h, st);
+    build_pyramid(f, fr, f->staging, width, height, w, h, st);
     fr.valid = true;
     HIPK(f, hipGetLastError());
     return EKFVIO_OK;
