@@ -1,12 +1,11 @@
-// ekf_vio_amd/csrc/fast.hip — frame ingest and landmark replenishment on the device.
+// ekf_vio_amd/csrc/fast.hip — landmark replenishment on the device.  (Frame::Frame's resize, F2, is part
+// of the pyramid kernel: klt.hip, resize_pixel.)
 //
 // Reference:
-//   Frame::Frame (include/ekf_vio/Frame.cpp:15-42): cv::resize(img, Size(cols/s, rows/s)), K / s
 //   EKFVIO::replenishFeatures (include/ekf_vio/EKFVIO.cpp:224-311): cv::FAST(img, kp, FAST_THRESHOLD, true),
 //     occupancy image of filled circles (radius MIN_NEW_FEATURE_DIST) around the landmarks' pixels, first fit
 //     over the keypoints in detector (raster) order, kill-box test, addNewFeatures(pixel2Metric(...)).
-// The arithmetic is OpenCV 3.x's (resize.cpp 8-bit INTER_LINEAR, fast.cpp / fast_score.cpp TYPE_9_16,
-// drawing.cpp Circle): everything is integer, so the kernels are bit-exact against oracle/fast_oracle.cpp.
+// The arithmetic is OpenCV 3.x's (fast.cpp / fast_score.cpp TYPE_9_16, drawing.cpp Circle): everything is integer, so the kernels are bit-exact against oracle/fast_oracle.cpp.
 //
 // Mapping: the FAST segment test + score are one thread per pixel (the 16 ring pixels become two
 // 16-bit masks, "9 contiguous" is four shift-ands on the doubled mask).  Non-maximum suppression and the
