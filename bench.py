@@ -156,14 +156,17 @@ def _textured_sequence(frames, dx=-1.4, dy=-0.45):
     return translated_sequence(base, frames, dx, dy)
 
 
-def full_loop(n_landmarks, device, frames=40, warm=6):
+def full_loop(n_landmarks, device, frames=40, warm=6, node_defaults=False):
     from ekf_vio_amd import EKFVIO, capi
     K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)
     prof = 8
     imgs = _textured_sequence(warm + frames + prof)
     # enough corners for N landmarks on this image: the reference defaults (threshold 50, 30 px apart) yield ~90
     thr, dist = (50, 30) if n_landmarks <= 64 else (20, 12)
-    v = EKFVIO(max_features=n_landmarks, device=device, replenish=1, fast_threshold=thr, min_new_feature_dist=dist)
+    extra = {}
+    if node_defaults:  # the node's own parameter defaults (Params.h): the frame is resized by 4 before anything else
+        extra["inverse_image_scale"] = 4
+    v = EKFVIO(max_features=n_landmarks, device=device, replenish=1, fast_threshold=thr, min_new_feature_dist=dist, **extra)
     e = v.tc_ekf
     numeric = 0
     for i in range(warm):
@@ -195,7 +198,8 @@ def full_loop(n_landmarks, device, frames=40, warm=6):
     return {"frames_per_s": frames / el, "ms_per_frame": 1e3 * el / frames, "landmarks": N, "landmarks_at_start": n_start,
             "landmarks_never_lost": tracked, "numeric_warnings": int(numeric), "state_finite": finite, "frames": frames,
             "image": "tests/golden/images/640_480_test_gray.png translated by (-1.4, -0.45) px per frame, fx = fy = 500",
-            "what": "ekfvio_step_image per frame: H2D frame, pyramid, process(dt), KLT (z from the tracker), update, replenishment (cfg.replenish=1, FAST threshold %d, %d px apart)" % (thr, dist),
+            "what": "ekfvio_step_image per frame: H2D frame, %spyramid, process(dt), KLT (z from the tracker), update, replenishment (cfg.replenish=1, FAST threshold %d, %d px apart)"
+                    % ("resize by 4 inside the " if node_defaults else "", thr, dist),
             "stage_us_per_frame": stage,
             "klt": {"pyramid_us": pyr_us, "track_us": trk_us, "tracks_per_s": (N / (trk_us * 1e-6)) if trk_us else None,
                     "pyramid_bytes": pyr_bytes,
@@ -406,9 +410,11 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_full_loop:
             try:
-                extra["full_loop"] = {"n64": full_loop(64, local), "n256": full_loop(256, local)}
+                extra["full_loop"] = {"n64": full_loop(64, local), "n256": full_loop(256, local),
+                                      "node_defaults_n100_scale4": full_loop(100, local, node_defaults=True)}
                 extra["klt"] = extra["full_loop"]["n256"].pop("klt")
                 extra["full_loop"]["n64"].pop("klt")
+                extra["full_loop"]["node_defaults_n100_scale4"].pop("klt")
             except Exception as ex:  # reported, never fatal for the headline metric
                 extra["full_loop"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:

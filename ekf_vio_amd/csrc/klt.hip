@@ -286,10 +286,19 @@ __global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __re
         // ends).  Smaller frames take the general reflection, rolled.
         constexpr int NL = (G::S * G::S + PYR_NT - 1) / PYR_NT;
         if (ra.on) {
-            // level 0 is the resized frame: every region entry is resized out of the full-size source on the fly
-#pragma unroll 1
-            for (int e = tid; e < G::S * G::S; e += PYR_NT)
-                R0[e] = resize_pixel(src, spitch, ra, reflect101(ox + e % G::S, w), reflect101(oy + e / G::S, h));
+            // level 0 is the resized frame: every region entry is resized out of the full-size source on the fly (unrolled:
+            // the four taps of all of a thread's entries are in flight together)
+            uint8_t v[NL];
+#pragma unroll
+            for (int it = 0; it < NL; it++) {
+                const int e = min(tid + PYR_NT * it, G::S * G::S - 1);
+                v[it] = resize_pixel(src, spitch, ra, reflect101(ox + e % G::S, w), reflect101(oy + e / G::S, h));
+            }
+#pragma unroll
+            for (int it = 0; it < NL; it++) {
+                const int e = tid + PYR_NT * it;
+                if (e < G::S * G::S) R0[e] = v[it];
+            }
         } else if (w >= G::S && h >= G::S) {
             uint8_t v[NL];
 #pragma unroll
