@@ -35,8 +35,11 @@ __global__ void init_sigma_kernel(float* P, int ld) {
 }
 
 // addNewFeatures (:58-94): new rows/columns are zero, new diagonal [hv, hv, dv]
+// k_dev != nullptr: the count comes from device memory (the first-fit selection's result, ekfvio_step_image: the host
+// learns it with the frame's status word, not in the middle of the frame)
 __global__ void add_features_kernel(float* P, int ld, int n_old, int k, float hv, float dv, float* mu, float* last_klt,
-                                    uint8_t* del_flag, const float* uv, int N_old, float inv_depth) {
+                                    uint8_t* del_flag, const float* uv, int N_old, float inv_depth, const int* k_dev) {
+    if (k_dev) k = *k_dev;
     const int n_new = n_old + 3 * k;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)3 * k * n_new;
          e += (size_t)gridDim.x * blockDim.x) {
@@ -78,11 +81,19 @@ int add_features_device(ekfvio_filter* f, int count) {
     const float inv_depth = (float)(1.0 / (double)depth);  // Feature.cpp:18  mu(2) = 1.0/depth
     hipLaunchKernelGGL(add_features_kernel, dim3(64), dim3(256), 0, f->stream, f->P, f->ldp, f->n, count,
                        f->cfg.default_point_homogenous_variance, f->cfg.default_point_depth_variance, f->mu,
-                       f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth);
+                       f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth, nullptr);
     HIPC(f, hipStreamSynchronize(f->stream));
     f->N += count;
     f->n += 3 * count;
     return EKFVIO_OK;
+}
+// The same with the count in device memory (at most max_features - N, by construction of the selection): enqueued only.
+// The caller adds the count to f->N / f->n once it has read it (wait_status's extra word).
+void add_features_enqueue_device_count(ekfvio_filter* f, const int* count_dev) {
+    const float inv_depth = (float)(1.0 / (double)f->cfg.default_point_depth);
+    hipLaunchKernelGGL(add_features_kernel, dim3(64), dim3(256), 0, f->stream, f->P, f->ldp, f->n, 0,
+                       f->cfg.default_point_homogenous_variance, f->cfg.default_point_depth_variance, f->mu,
+                       f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth, count_dev);
 }
 
 // The host's wait at the end of a frame.  A one-thread kernel behind everything else on the stream writes the status
@@ -90,13 +101,14 @@ int add_features_device(ekfvio_filter* f, int count) {
 // device-to-host copy plus hipStreamSynchronize this saves the copy's command and the interrupt-driven wake-up (≈10 us
 // per frame).  Polling is bounded: after 300 us (a long device-resident run is in flight) the host blocks in
 // hipStreamSynchronize like before.
-__global__ void publish_status_kernel(const int* __restrict__ info, int* host_word, int seq) {
+__global__ void publish_status_kernel(const int* __restrict__ info, int* host_word, int seq, const int* __restrict__ extra) {
     host_word[0] = info[0];
+    host_word[2] = extra ? *extra : 0;
     __hip_atomic_store(host_word + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-int wait_status(ekfvio_filter* f, int* status) {
+int wait_status(ekfvio_filter* f, int* status, const int* extra_dev, int* extra_out) {
     const int seq = ++f->status_seq;
-    hipLaunchKernelGGL(publish_status_kernel, dim3(1), dim3(1), 0, f->stream, f->info, f->d_hinfo, seq);
+    hipLaunchKernelGGL(publish_status_kernel, dim3(1), dim3(1), 0, f->stream, f->info, f->d_hinfo, seq, extra_dev);
     HIPC(f, hipGetLastError());
     volatile int* hw = f->h_info;
     const auto t0 = std::chrono::steady_clock::now();
@@ -112,6 +124,7 @@ int wait_status(ekfvio_filter* f, int* status) {
         return EKFVIO_EDEVICE;
     }
     *status = hw[0];
+    if (extra_out) *extra_out = hw[2];
     return EKFVIO_OK;
 }
 

@@ -241,9 +241,12 @@ void launch_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[
 int fast_alloc(ekfvio_filter* f);
 void fast_free(ekfvio_filter* f);
 // Waits for everything on the handle's stream and returns the factorisation's status word through *status (api.hip).
-int wait_status(ekfvio_filter* f, int* status);
+// extra_dev (may be null): one more device word delivered with it through *extra_out.
+int wait_status(ekfvio_filter* f, int* status, const int* extra_dev = nullptr, int* extra_out = nullptr);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
 int add_features_device(ekfvio_filter* f, int k);
+void add_features_enqueue_device_count(ekfvio_filter* f, const int* count_dev);  // enqueue only; the caller updates N / n
+int replenish_enqueue(ekfvio_filter* f, int* enqueued);  // fast.hip: FAST + first-fit selection, count left in f->fast_counts[1]
 // The two P-update GEMM launches of an update with m measurement rows, `reps` times, into scratch (P2, Gm): the
 // filter state is not touched.  For timing the kernel under its production shape (ekfvio_profile_update_gemms).
 int launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);  // returns the GEMM launches per repetition (1 with the Schur sweep, else 2)

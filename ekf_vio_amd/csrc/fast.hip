@@ -242,19 +242,21 @@ __device__ inline void stamp_circle(const OccMask<LDSMASK>& mask, int w, int h, 
     }
 }
 
-// replenishFeatures' selection: one wavefront.  The global mask (LDSMASK = false) is zeroed by the caller.
+// replenishFeatures' selection.  Four wavefronts clear the mask and stamp the existing landmarks' circles (order-free:
+// bit ORs; every wavefront fetches 64 landmark pixels at once and takes every fourth); the first fit itself is sequential
+// by definition and stays with wavefront 0.  The global mask (LDSMASK = false) is zeroed by the caller.
 template <bool LDSMASK>
-__global__ __launch_bounds__(64) void replenish_select_kernel(const int* __restrict__ kp_xy, const int* __restrict__ kp_count, int cap_kp,
+__global__ __launch_bounds__(256) void replenish_select_kernel(const int* __restrict__ kp_xy, const int* __restrict__ kp_count, int cap_kp,
                                                               const float* __restrict__ mu, int N_old, float fx, float fy, float cx,
                                                               float cy, int num_features, int w, int h, int radius, int kill_pad,
                                                               unsigned* gmask, int* new_xy, float* new_uv, int* new_count) {
     __shared__ unsigned lmask[LDSMASK ? OCC_LDS_WORDS : 1];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     OccMask<LDSMASK> mask;
     mask.wpr = (w + 31) / 32;
     mask.words = LDSMASK ? lmask : gmask;
     if (LDSMASK) {
-        for (int i = lane; i < mask.wpr * h; i += 64) lmask[i] = 0u;
+        for (int i = threadIdx.x; i < mask.wpr * h; i += 256) lmask[i] = 0u;
         __syncthreads();
     }
     int hw[OCC_PASSES];
@@ -264,12 +266,16 @@ __global__ __launch_bounds__(64) void replenish_select_kernel(const int* __restr
         hw[q] = (rr <= radius) ? circle_half_width(radius, rr) : -1;
     }
     // occupancy of the existing landmarks: circle at cv::Point(getPixel(f)) = cvRound of (u*fx + cx, v*fy + cy)
-    for (int i = 0; i < N_old; i++) {
-        const float u = mu[EKF_BASE + 3 * i], v = mu[EKF_BASE + 3 * i + 1];
-        const int px = __float2int_rn(u * fx + cx), py = __float2int_rn(v * fy + cy);
-        stamp_circle(mask, w, h, px, py, radius, lane, hw);
+    for (int i0 = 0; i0 < N_old; i0 += 64) {
+        const int il = min(i0 + lane, N_old - 1);
+        const float u = mu[EKF_BASE + 3 * il], v = mu[EKF_BASE + 3 * il + 1];
+        const int mypx = __float2int_rn(u * fx + cx), mypy = __float2int_rn(v * fy + cy);
+        const int cnt = min(64, N_old - i0);
+        for (int j = wave; j < cnt; j += 4) stamp_circle(mask, w, h, __shfl(mypx, j, 64), __shfl(mypy, j, 64), radius, lane, hw);
     }
-    __syncthreads();  // one wavefront: orders the mask writes before the reads below (lgkmcnt / vmcnt drained)
+    if (!LDSMASK) __threadfence();  // the other wavefronts' ORs went to the global mask
+    __syncthreads();
+    if (wave != 0) return;  // (the barriers below are wavefront 0's alone from here on)
     int wanted = num_features - N_old, added = 0;
     const int nk = min(*kp_count, cap_kp);
     for (int c0 = 0; c0 < nk && added < wanted; c0 += 64) {
@@ -402,6 +408,42 @@ int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur) {
     return EKFVIO_OK;
 }
 
+// FAST on the current frame and the first-fit selection, enqueued only: the new landmarks' pixels are in f->new_xy, their
+// metric positions in f->zmeas, their number in f->fast_counts[1].  *enqueued = 0 if the filter is full (nothing to do).
+int replenish_enqueue(ekfvio_filter* f, int* enqueued) {
+    *enqueued = 0;
+    if (!f) return EKFVIO_EINVAL;
+    if (f->cfg.fast_blur_sigma != 0.f && !(f->cfg.fast_blur_sigma > 0.f)) {
+        f->last_error = "fast_blur_sigma must be >= 0";  // cv::GaussianBlur would derive sigma from the kernel size
+        return EKFVIO_EINVAL;
+    }
+    if (f->cfg.min_new_feature_dist < 0 || f->cfg.min_new_feature_dist > 64 * OCC_PASSES / 2 - 1) {
+        f->last_error = "min_new_feature_dist must be in [0, 63]";
+        return EKFVIO_EINVAL;
+    }
+    HIPF(f, hipSetDevice(f->device));
+    if (f->N >= f->cfg.max_features) return EKFVIO_OK;  // "if (tc_ekf.features.size() < NUM_FEATURES)" (:236)
+    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1, f->cfg.fast_blur_sigma != 0.f);
+    if (rc != EKFVIO_OK) return rc;
+    const KltFrame& fr = f->frames[f->cur];
+    const int w = fr.w[0], h = fr.h[0];
+    float fx, fy, cx, cy;
+    klt_intrinsics(f, fr.K, &fx, &fy, &cx, &cy);
+    const size_t mask_words = (size_t)((w + 31) / 32) * h;
+    if (mask_words <= OCC_LDS_WORDS) {
+        hipLaunchKernelGGL(replenish_select_kernel<true>, dim3(1), dim3(256), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
+                           f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
+                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
+    } else {
+        HIPF(f, hipMemsetAsync(f->occ_mask, 0, mask_words * sizeof(unsigned), f->stream));
+        hipLaunchKernelGGL(replenish_select_kernel<false>, dim3(1), dim3(256), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
+                           f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
+                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
+    }
+    *enqueued = 1;
+    return EKFVIO_OK;
+}
+
 extern "C" {
 
 int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score, int32_t* count) {
@@ -439,37 +481,13 @@ int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out) {
 // EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame
 int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy) {
     if (!f) return EKFVIO_EINVAL;
-    if (f->cfg.fast_blur_sigma != 0.f && !(f->cfg.fast_blur_sigma > 0.f)) {
-        f->last_error = "fast_blur_sigma must be >= 0";  // cv::GaussianBlur would derive sigma from the kernel size
-        return EKFVIO_EINVAL;
-    }
-    if (f->cfg.min_new_feature_dist < 0 || f->cfg.min_new_feature_dist > 64 * OCC_PASSES / 2 - 1) {
-        f->last_error = "min_new_feature_dist must be in [0, 63]";
-        return EKFVIO_EINVAL;
-    }
-    HIPF(f, hipSetDevice(f->device));
     if (added) *added = 0;
-    if (f->N >= f->cfg.max_features) return EKFVIO_OK;  // "if (tc_ekf.features.size() < NUM_FEATURES)" (:236)
-    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1, f->cfg.fast_blur_sigma != 0.f);
+    int enq = 0;
+    int rc = replenish_enqueue(f, &enq);
+    if (rc != EKFVIO_OK || !enq) return rc;
+    int k = 0, bad = 0;
+    rc = wait_status(f, &bad, f->fast_counts + 1, &k);  // the count through the polled host word (no pageable copy)
     if (rc != EKFVIO_OK) return rc;
-    const KltFrame& fr = f->frames[f->cur];
-    const int w = fr.w[0], h = fr.h[0];
-    float fx, fy, cx, cy;
-    klt_intrinsics(f, fr.K, &fx, &fy, &cx, &cy);
-    const size_t mask_words = (size_t)((w + 31) / 32) * h;
-    if (mask_words <= OCC_LDS_WORDS) {
-        hipLaunchKernelGGL(replenish_select_kernel<true>, dim3(1), dim3(64), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
-                           f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
-                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
-    } else {
-        HIPF(f, hipMemsetAsync(f->occ_mask, 0, mask_words * sizeof(unsigned), f->stream));
-        hipLaunchKernelGGL(replenish_select_kernel<false>, dim3(1), dim3(64), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
-                           f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
-                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
-    }
-    int k = 0;
-    HIPF(f, hipMemcpyAsync(&k, f->fast_counts + 1, sizeof(int), hipMemcpyDeviceToHost, f->stream));
-    HIPF(f, hipStreamSynchronize(f->stream));
     if (k > 0 && new_px_xy) HIPF(f, hipMemcpyAsync(new_px_xy, f->new_xy, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, f->stream));
     if (k > 0) {
         rc = add_features_device(f, k);  // uv already in f->zmeas

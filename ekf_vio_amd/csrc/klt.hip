@@ -1184,14 +1184,22 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         launch_update(f, 0, f->zmeas, f->Rmeas, f->pass, nullptr, 0, false, true);
     }
     HIPK(f, hipGetLastError());
-    if (f->cfg.replenish) {  // "try to get more features if needed" (:172)
-        rc = ekfvio_replenish(f, nullptr, nullptr);
+    // "try to get more features if needed" (:172): detection, first-fit selection and the growth of the state are
+    // enqueued behind the update with the number of new landmarks left on the device; the host reads it with the status
+    // word, in the frame's single wait, and only then counts the landmarks in
+    int replenishing = 0;
+    if (f->cfg.replenish) {
+        rc = replenish_enqueue(f, &replenishing);
         if (rc != EKFVIO_OK) return rc;
+        if (replenishing) add_features_enqueue_device_count(f, f->fast_counts + 1);
     }
-    // the frame's single host wait: status word of the factorisation
-    int bad = 0;
-    rc = wait_status(f, &bad);
+    int bad = 0, added = 0;
+    rc = wait_status(f, &bad, replenishing ? f->fast_counts + 1 : nullptr, &added);
     if (rc != EKFVIO_OK) return rc;
+    if (added > 0) {
+        f->N += added;
+        f->n += 3 * added;
+    }
     if (bad) {
         status = EKFVIO_ENUMERIC;
         HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
