@@ -138,13 +138,12 @@ struct ekfvio_filter {
     uint8_t* h_image = nullptr;    // pinned host staging: the caller's frame is copied here, so its buffer is free on return without a stream sync
     // --- frame ingest + replenishment (fast.hip) ---
     uint8_t* blurred = nullptr;    // replenishFeatures' cv::GaussianBlur output (only with cfg.fast_blur_sigma != 0)
-    short* fast_score = nullptr;   // FAST score map of level 0 (-1 = no corner)
+    unsigned* fast_row_kp = nullptr;  // [w*h] per image row its keypoints in x order, (score << 16) | x
     int* fast_kp_xy = nullptr;     // keypoints in raster order
     short* fast_kp_score = nullptr;
     int fast_kp_cap = 0;
     uint8_t* occ_mask = nullptr;   // replenishFeatures' checkImg as a bit mask (global fallback for large frames)
-    int* fast_row_cnt = nullptr;   // [max_image_height] keypoints per row / exclusive row offsets
-    int* fast_row_off = nullptr;
+    int* fast_row_cnt = nullptr;   // [max_image_height] keypoints per row
     int* new_xy = nullptr;         // pixels of the landmarks added by the last replenishment
     int* fast_counts = nullptr;    // [0] keypoints found, [1] landmarks added
     double t_stamp = 0;

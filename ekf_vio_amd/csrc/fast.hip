@@ -7,13 +7,13 @@
 //     over the keypoints in detector (raster) order, kill-box test, addNewFeatures(pixel2Metric(...)).
 // The arithmetic is OpenCV 3.x's (fast.cpp / fast_score.cpp TYPE_9_16, drawing.cpp Circle): everything is integer, so the kernels are bit-exact against oracle/fast_oracle.cpp.
 //
-// Mapping: the FAST segment test + score are one thread per pixel (the 16 ring pixels become two
-// 16-bit masks, "9 contiguous" is four shift-ands on the doubled mask).  Non-maximum suppression and the
-// raster-order compaction are three small launches (keypoints per row, scan over the rows, ordered write with
-// ballot prefixes inside a row), which keeps cv::FAST's keypoint order without a sort.  The first-fit selection is inherently sequential in
-// keypoint order: one wavefront takes 64 keypoints at a time, tests them against the occupancy mask in
-// parallel, accepts the first free one, stamps its circle (one lane per circle row, bit mask in LDS) and
-// re-tests the rest.
+// Mapping: detection is two launches: a workgroup per image row scores the row and its two neighbours in LDS (the 16
+// ring pixels become two 16-bit masks, "9 contiguous" is four shift-ands on the doubled mask), suppresses non-maxima and
+// appends the survivors in x order to the row's own list; one workgroup then scans the row counts and copies the lists in
+// row order, which keeps cv::FAST's keypoint order without a sort.  The first-fit selection is inherently sequential
+// in keypoint order: one wavefront takes 64 keypoints at a time, tests them against the occupancy mask in parallel,
+// accepts the first free one, stamps its circle (one lane per circle row, bit mask in LDS) and re-tests the rest; four
+// wavefronts prepare the mask (existing landmarks' circles) before that.
 #include "common.h"
 
 #define HIPF(f, expr)                                                              \
@@ -27,10 +27,9 @@
 
 namespace {
 
-// FAST-9/16 segment test + cornerScore<16>; score map: -1 = no corner.  img points at pixel (0,0) of a pitched image.
-__global__ void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h, int pitch, int threshold, short* __restrict__ score) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+// FAST-9/16 segment test + cornerScore<16> at pixel (x, y): -1 = no corner (or inside the 3-pixel frame cv::FAST skips).
+// img points at pixel (0,0) of a pitched image.
+__device__ inline short fast_score_at(const uint8_t* __restrict__ img, int w, int h, int pitch, int threshold, int x, int y) {
     short out = -1;
     if (x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
         const uint8_t* p = img + (size_t)y * pitch + x;
@@ -87,35 +86,69 @@ __global__ void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h,
             out = (short)(-b0 - 1);
         }
     }
-    score[(size_t)y * w + x] = out;
+    return out;
 }
 
-// non-maximum suppression: strict > against the 8 neighbours of the score map (fast.cpp)
-__device__ inline bool fast_keep(const short* __restrict__ score, int w, int h, int x, int y, int nonmax) {
-    if (x < 3 || x >= w - 3) return false;
-    const short s = score[(size_t)y * w + x];
-    if (s < 0) return false;
-    if (!nonmax) return true;
-    const short* r0 = score + (size_t)(y - 1) * w + x;
-    const short* r1 = score + (size_t)y * w + x;
-    const short* r2 = score + (size_t)(y + 1) * w + x;
-    return s > r0[-1] && s > r0[0] && s > r0[1] && s > r1[-1] && s > r1[1] && s > r2[-1] && s > r2[0] && s > r2[1];
-}
-
-// raster-order compaction in three small launches: keypoints per row, exclusive scan over the rows, ordered write
-__global__ __launch_bounds__(256) void fast_row_count_kernel(const short* __restrict__ score, int w, int h, int nonmax, int* row_cnt) {
-    __shared__ int s_part[4];
-    const int y = blockIdx.x, tid = threadIdx.x;
-    int c = 0;
-    if (y >= 3 && y < h - 3)
-        for (int x = tid; x < w; x += 256) c += fast_keep(score, w, h, x, y, nonmax) ? 1 : 0;
+// Detection in two launches (was four: score map, keypoints per row, scan, ordered write).
+// fast_rows_kernel: one workgroup per image row.  In chunks of 256 columns it scores the row and its two neighbours into
+// LDS (each row's scores are formed three times over the grid: cheaper than a launch and a score map in HBM), applies the
+// non-maximum suppression (strict > against the 8 neighbours, fast.cpp) and appends the survivors, in x order, to the
+// row's own list (x and score packed into one word) with a ballot prefix; row_cnt[y] = their number.
+// fast_gather_kernel: one workgroup scans the row counts and copies the rows' lists, in row order, into the keypoint
+// arrays: cv::FAST's raster order without a sort.
+#define FAST_CHUNK 256
+__global__ __launch_bounds__(FAST_CHUNK) void fast_rows_kernel(const uint8_t* __restrict__ img, int w, int h, int pitch, int threshold,
+                                                               int nonmax, unsigned* __restrict__ row_kp, int* __restrict__ row_cnt) {
+    __shared__ short sc[3][FAST_CHUNK + 2];
+    __shared__ int s_w[FAST_CHUNK / 64];
+    __shared__ int s_base;
+    const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (y < 3 || y >= h - 3) {  // cv::FAST's frame: no keypoints
+        if (tid == 0) row_cnt[y] = 0;
+        return;
+    }
+    if (tid == 0) s_base = 0;
+    unsigned* out = row_kp + (size_t)y * w;
+    for (int x0 = 0; x0 < w; x0 += FAST_CHUNK) {
+        __syncthreads();  // the previous chunk's readers are done; s_base is visible
+        // columns x0 - 1 .. x0 + FAST_CHUNK of rows y - 1, y, y + 1 (the two extra columns by the first two threads)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-    if ((tid & 63) == 0) s_part[tid >> 6] = c;
+        for (int r = 0; r < 3; r++) {
+            const int x = x0 + tid;
+            sc[r][tid + 1] = (x < w) ? fast_score_at(img, w, h, pitch, threshold, x, y - 1 + r) : (short)-1;
+        }
+        if (tid < 2) {
+            const int x = tid == 0 ? x0 - 1 : x0 + FAST_CHUNK;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+                sc[r][tid == 0 ? 0 : FAST_CHUNK + 1] = (x >= 0 && x < w) ? fast_score_at(img, w, h, pitch, threshold, x, y - 1 + r) : (short)-1;
+        }
+        __syncthreads();
+        const int x = x0 + tid;
+        const short s = sc[1][tid + 1];
+        bool keep = x >= 3 && x < w - 3 && s >= 0;
+        if (keep && nonmax)
+            keep = s > sc[0][tid] && s > sc[0][tid + 1] && s > sc[0][tid + 2] && s > sc[1][tid] && s > sc[1][tid + 2] && s > sc[2][tid] &&
+                   s > sc[2][tid + 1] && s > sc[2][tid + 2];
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_w[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < FAST_CHUNK / 64; q++) {
+            before += (q < wv) ? s_w[q] : 0;
+            tot += s_w[q];
+        }
+        const int base = s_base;
+        if (keep) out[base + before + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned)(unsigned short)s << 16) | (unsigned)x;
+        __syncthreads();
+        if (tid == 0) s_base = base + tot;
+    }
     __syncthreads();
-    if (tid == 0) row_cnt[y] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (tid == 0) row_cnt[y] = s_base;
 }
-__global__ __launch_bounds__(1024) void fast_row_scan_kernel(const int* __restrict__ row_cnt, int h, int* row_off, int* total) {
+__global__ __launch_bounds__(1024) void fast_gather_kernel(const unsigned* __restrict__ row_kp, const int* __restrict__ row_cnt, int w, int h,
+                                                           int cap, int* __restrict__ kp_xy, short* __restrict__ kp_score, int* total) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -139,47 +172,22 @@ __global__ __launch_bounds__(1024) void fast_row_scan_kernel(const int* __restri
             tot += s_w[q];
         }
         const int carry = s_carry;
-        if (y < h) row_off[y] = carry + before + incl - c;
+        const int off0 = carry + before + incl - c;  // this row's first slot
+        const unsigned* src = row_kp + (size_t)y * w;
+        for (int i = 0; i < c; i++) {
+            const int o = off0 + i;
+            if (o < cap) {
+                const unsigned v = src[i];
+                kp_xy[2 * o] = (int)(v & 0xffffu);
+                kp_xy[2 * o + 1] = y;
+                kp_score[o] = (short)(v >> 16);
+            }
+        }
         __syncthreads();
         if (tid == 0) s_carry = carry + tot;
         __syncthreads();
     }
     if (tid == 0) *total = s_carry;
-}
-__global__ __launch_bounds__(256) void fast_row_write_kernel(const short* __restrict__ score, int w, int h, int nonmax, int cap,
-                                                             const int* __restrict__ row_off, int* __restrict__ kp_xy,
-                                                             short* __restrict__ kp_score) {
-    __shared__ int s_w[4];
-    __shared__ int s_base;
-    const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (y < 3 || y >= h - 3) return;
-    if (tid == 0) s_base = row_off[y];
-    __syncthreads();
-    for (int x0 = 0; x0 < w; x0 += 256) {
-        const int x = x0 + tid;
-        const bool keep = x < w && fast_keep(score, w, h, x, y, nonmax);
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_w[wv] = __popcll(bal);
-        __syncthreads();
-        int before = 0, tot = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            before += (q < wv) ? s_w[q] : 0;
-            tot += s_w[q];
-        }
-        const int base = s_base;
-        if (keep) {
-            const int o = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-            if (o < cap) {
-                kp_xy[2 * o] = x;
-                kp_xy[2 * o + 1] = y;
-                kp_score[o] = score[(size_t)y * w + x];
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_base = base + tot;
-        __syncthreads();
-    }
 }
 
 // drawing.cpp Circle(), filled: half-width of the span in row cy + dyrow (-1: the row is outside the circle)
@@ -363,13 +371,12 @@ int fast_alloc(ekfvio_filter* f) {
     const ekfvio_config& c = f->cfg;
     const size_t px = (size_t)c.max_image_width * c.max_image_height;
     if (c.fast_blur_sigma != 0.f) HIPF(f, hipMalloc((void**)&f->blurred, px));
-    HIPF(f, hipMalloc((void**)&f->fast_score, px * sizeof(short)));
+    HIPF(f, hipMalloc((void**)&f->fast_row_kp, px * sizeof(unsigned)));  // per image row: its keypoints in x order, (score << 16) | x
     f->fast_kp_cap = (int)(px / 4 + 1);
     HIPF(f, hipMalloc((void**)&f->fast_kp_xy, (size_t)f->fast_kp_cap * 2 * sizeof(int)));
     HIPF(f, hipMalloc((void**)&f->fast_kp_score, (size_t)f->fast_kp_cap * sizeof(short)));
     HIPF(f, hipMalloc((void**)&f->occ_mask, ((size_t)(c.max_image_width + 31) / 32) * c.max_image_height * sizeof(unsigned)));
     HIPF(f, hipMalloc((void**)&f->fast_row_cnt, (size_t)c.max_image_height * sizeof(int)));
-    HIPF(f, hipMalloc((void**)&f->fast_row_off, (size_t)c.max_image_height * sizeof(int)));
     const int maxf = c.max_features > 0 ? c.max_features : 1;
     HIPF(f, hipMalloc((void**)&f->new_xy, (size_t)maxf * 2 * sizeof(int)));
     HIPF(f, hipMalloc((void**)&f->fast_counts, 4 * sizeof(int)));
@@ -377,7 +384,7 @@ int fast_alloc(ekfvio_filter* f) {
 }
 
 void fast_free(ekfvio_filter* f) {
-    void* ptrs[] = {f->blurred, f->fast_score, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt, f->fast_row_off};
+    void* ptrs[] = {f->blurred, f->fast_row_kp, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->new_xy, f->fast_counts, f->fast_row_cnt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -400,11 +407,10 @@ int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur) {
         img0 = f->blurred;
         pitch = w;
     }
-    hipLaunchKernelGGL(fast_score_kernel, dim3((w + 255) / 256, h), dim3(256), 0, f->stream, img0, w, h, pitch, threshold, f->fast_score);
-    hipLaunchKernelGGL(fast_row_count_kernel, dim3(h), dim3(256), 0, f->stream, f->fast_score, w, h, nonmax, f->fast_row_cnt);
-    hipLaunchKernelGGL(fast_row_scan_kernel, dim3(1), dim3(1024), 0, f->stream, f->fast_row_cnt, h, f->fast_row_off, f->fast_counts);
-    hipLaunchKernelGGL(fast_row_write_kernel, dim3(h), dim3(256), 0, f->stream, f->fast_score, w, h, nonmax, f->fast_kp_cap, f->fast_row_off,
-                       f->fast_kp_xy, f->fast_kp_score);
+    hipLaunchKernelGGL(fast_rows_kernel, dim3(h), dim3(FAST_CHUNK), 0, f->stream, img0, w, h, pitch, threshold, nonmax, f->fast_row_kp,
+                       f->fast_row_cnt);
+    hipLaunchKernelGGL(fast_gather_kernel, dim3(1), dim3(1024), 0, f->stream, f->fast_row_kp, f->fast_row_cnt, w, h, f->fast_kp_cap,
+                       f->fast_kp_xy, f->fast_kp_score, f->fast_counts);
     return EKFVIO_OK;
 }
 
