@@ -104,27 +104,48 @@ __device__ inline short sat_short_rn(float v) {
     const int i = __float2int_rn(v);  // round half to even = cvRound
     return (short)min(32767, max(-32768, i));
 }
-__device__ inline uint8_t resize_pixel(const uint8_t* __restrict__ src, int sstride, const ResizeArgs& ra, int dx, int dy) {
+// The separable part of a destination coordinate: source index pair and the two weights (x: clamped as resize.cpp's
+// xofs / alpha tables are; y: the row indices are clamped, the weights are not).
+struct ResizeTap {
+    int s0, s1;
+    short w0, w1;
+};
+__device__ inline ResizeTap resize_tap_x(const ResizeArgs& ra, int dx) {
     float fx = (float)((dx + 0.5) * ra.scale_x - 0.5);
     int sx = (int)floorf(fx);
     fx -= sx;
     if (sx < 0) { fx = 0; sx = 0; }
     if (sx >= ra.sw - 1) { fx = 0; sx = ra.sw - 1; }
+    return {sx, min(sx + 1, ra.sw - 1), sat_short_rn((1.f - fx) * 2048), sat_short_rn(fx * 2048)};
+}
+__device__ inline ResizeTap resize_tap_y(const ResizeArgs& ra, int dy) {
     float fy = (float)((dy + 0.5) * ra.scale_y - 0.5);
     const int sy = (int)floorf(fy);
     fy -= sy;
-    const int a0 = sat_short_rn((1.f - fx) * 2048), a1 = sat_short_rn(fx * 2048);
-    const int b0 = sat_short_rn((1.f - fy) * 2048), b1 = sat_short_rn(fy * 2048);
-    const int sx1 = min(sx + 1, ra.sw - 1);
-    const int sy0 = min(max(sy, 0), ra.sh - 1), sy1 = min(max(sy + 1, 0), ra.sh - 1);
-    const uint8_t *S0 = src + (size_t)sy0 * sstride, *S1 = src + (size_t)sy1 * sstride;
-    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
+    return {min(max(sy, 0), ra.sh - 1), min(max(sy + 1, 0), ra.sh - 1), sat_short_rn((1.f - fy) * 2048), sat_short_rn(fy * 2048)};
+}
+__device__ inline uint8_t resize_combine(const uint8_t* __restrict__ src, int sstride, const ResizeTap& tx, const ResizeTap& ty) {
+    const uint8_t *S0 = src + (size_t)ty.s0 * sstride, *S1 = src + (size_t)ty.s1 * sstride;
+    const int a0 = tx.w0, a1 = tx.w1, b0 = ty.w0, b1 = ty.w1;
+    const int r0 = S0[tx.s0] * a0 + S0[tx.s1] * a1, r1 = S1[tx.s0] * a0 + S1[tx.s1] * a1;
     return (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
 }
 
 // calls fn(X) for every X in [-KLT_BORDER, w + KLT_BORDER) other than x itself whose reflect-101 image is x (0 <= x < w)
 template <class F>
 __device__ __forceinline__ void for_mirror_images(int x, int w, F&& fn) {
+    if (w >= 14) {
+        // period P = 2 (w - 1) >= 26 against a padded width of w + 48: the images x + k P and -x + k P with k in -1 .. 2 are
+        // all there can be (no division: this is the path of every pyramid level narrower than two borders plus two)
+        const int P = 2 * (w - 1);
+#pragma unroll
+        for (int k = -1; k <= 2; k++) {
+            const int X1 = x + k * P, X2 = -x + k * P;
+            if (X1 != x && X1 >= -KLT_BORDER && X1 < w + KLT_BORDER) fn(X1);
+            if (x != 0 && x != w - 1 && X2 >= -KLT_BORDER && X2 < w + KLT_BORDER) fn(X2);
+        }
+        return;
+    }
     if (w == 1) {
         for (int X = -KLT_BORDER; X < 1 + KLT_BORDER; X++)
             if (X != x) fn(X);
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __re
     // diagnostic phase stamps of one interior workgroup (scripts/klt_timing.py); dbg is null in production
 #define PSTAMP(slot)                                                                                                     \
     do {                                                                                                                 \
-        if (dbg && blockIdx.x == 5 && blockIdx.y == 5 && threadIdx.x == 0) dbg[940 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+        if (dbg && blockIdx.x == 2 && blockIdx.y == 2 && threadIdx.x == 0) dbg[940 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
     PSTAMP(0);
     const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;
@@ -288,11 +309,16 @@ __global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __re
         if (ra.on) {
             // level 0 is the resized frame: every region entry is resized out of the full-size source on the fly (unrolled:
             // the four taps of all of a thread's entries are in flight together)
+            // the coordinate arithmetic (double) is separable: one table entry per region column and per region row
+            __shared__ ResizeTap s_tx[G::S], s_ty[G::S];
+            if (tid < G::S) s_tx[tid] = resize_tap_x(ra, reflect101(ox + tid, w));
+            else if (tid < 2 * G::S) s_ty[tid - G::S] = resize_tap_y(ra, reflect101(oy + tid - G::S, h));
+            __syncthreads();
             uint8_t v[NL];
 #pragma unroll
             for (int it = 0; it < NL; it++) {
                 const int e = min(tid + PYR_NT * it, G::S * G::S - 1);
-                v[it] = resize_pixel(src, spitch, ra, reflect101(ox + e % G::S, w), reflect101(oy + e / G::S, h));
+                v[it] = resize_combine(src, spitch, s_tx[e % G::S], s_ty[e / G::S]);
             }
 #pragma unroll
             for (int it = 0; it < NL; it++) {

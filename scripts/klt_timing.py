@@ -38,13 +38,13 @@ for lv in (3, 2, 1, 0):
     print("  level %d: staging loads %6d  template + A %6d  %2d iterations %6d (%.0f each)" %
           (lv, s_[2 + o] - s_[1 + o], s_[3 + o] - s_[2 + o], s_[5 + o], s_[4 + o] - s_[3 + o], (s_[4 + o] - s_[3 + o]) / max(s_[5 + o], 1)))
 
-# phase stamps of the pyramid kernel (workgroup (5,5), an interior tile)
+# phase stamps of the pyramid kernel (workgroup (2,2), an interior tile)
 v.tc_ekf.lib.ekfvio_test_sweep_stamps(v.tc_ekf.h, 1, None)
 v.tracker.push_frame(a, K)
 v.tc_ekf.lib.ekfvio_test_sweep_stamps(v.tc_ekf.h, 1, buf)
 p = list(buf)[940:950]
 names = ["level-0 region loads", "level-0 stores", "pyrDown 1", "level-1 stores", "level 2", "level 3"]
-print("pyramid kernel, workgroup (5,5) (cycles): " + "  ".join("%s %d" % (names[i], p[i + 1] - p[i]) for i in range(6)) + "  | total %d" % (p[6] - p[0]))
+print("pyramid kernel, workgroup (2,2) (cycles): " + "  ".join("%s %d" % (names[i], p[i + 1] - p[i]) for i in range(6)) + "  | total %d" % (p[6] - p[0]))
 import numpy as np
 t = np.array(list(buf)[:600], np.int64).reshape(300, 2)
 t0 = t[:, 0].min()
@@ -54,3 +54,15 @@ print("  all 300 workgroups (us after the first started): starts min %.2f median
 d = (en_ - st_).reshape(15, 20)
 print("  durations by tile row (us): " + " ".join("%.1f" % x for x in d.mean(axis=1)))
 print("  durations of tile row 0: " + " ".join("%.1f" % x for x in d[0]))
+
+# the node's default geometry: a 640x480 upload resized by 4 inside the pyramid kernel (20 workgroups, 3 levels)
+v4 = EKFVIO(max_features=n, inverse_image_scale=4)
+v4.tracker.push_frame(a, K)
+v4.tc_ekf.lib.ekfvio_test_sweep_stamps(v4.tc_ekf.h, 1, None)
+v4.tracker.push_frame(b, K)
+v4.tc_ekf.lib.ekfvio_test_sweep_stamps(v4.tc_ekf.h, 1, buf)
+p = list(buf)[940:950]
+print("pyramid kernel with the resize by 4, workgroup (2,2) (cycles): " + "  ".join("%s %d" % (names[i], p[i + 1] - p[i]) for i in range(6)) + "  | total %d" % (p[6] - p[0]))
+t = np.array(list(buf)[:40], np.int64).reshape(20, 2)
+t0 = t[:, 0].min()
+print("  all 20 workgroups (us): ends min %.2f max %.2f; durations min %.2f median %.2f max %.2f" % (((t[:, 1] - t0) / 100.0).min(), ((t[:, 1] - t0) / 100.0).max(), ((t[:, 1] - t[:, 0]) / 100.0).min(), np.median((t[:, 1] - t[:, 0]) / 100.0), ((t[:, 1] - t[:, 0]) / 100.0).max()))
