@@ -156,7 +156,7 @@ def _textured_sequence(frames, dx=-1.4, dy=-0.45):
     return translated_sequence(base, frames, dx, dy)
 
 
-def full_loop(n_landmarks, device, frames=40, warm=6, node_defaults=False):
+def full_loop(n_landmarks, device, frames=40, warm=6, node_defaults=False, outputs=False):
     from ekf_vio_amd import EKFVIO, capi
     K = np.array([500.0, 0, 320.0, 0, 500.0, 240.0, 0, 0, 1.0], np.float32)
     prof = 8
@@ -176,6 +176,9 @@ def full_loop(n_landmarks, device, frames=40, warm=6, node_defaults=False):
     t0 = time.perf_counter()
     for i in range(warm, warm + frames):
         numeric += v.addFrame(i / 30.0, imgs[i], K) == capi.ENUMERIC
+        if outputs:  # what the node publishes per frame (EKFVIO.cpp:444-518): odometry and the landmark cloud
+            v.odometry()
+            v.points()
     e.synchronize()
     el = time.perf_counter() - t0
     st = e.get_state()
@@ -199,7 +202,8 @@ def full_loop(n_landmarks, device, frames=40, warm=6, node_defaults=False):
             "landmarks_never_lost": tracked, "numeric_warnings": int(numeric), "state_finite": finite, "frames": frames,
             "image": "tests/golden/images/640_480_test_gray.png translated by (-1.4, -0.45) px per frame, fx = fy = 500",
             "what": "ekfvio_step_image per frame: H2D frame, %spyramid, process(dt), KLT (z from the tracker), update, replenishment (cfg.replenish=1, FAST threshold %d, %d px apart)"
-                    % ("resize by 4 inside the " if node_defaults else "", thr, dist),
+                    % ("resize by 4 inside the " if node_defaults else "", thr, dist)
+                    + ("; then the node's per-frame outputs: odometry (ekfvio_get_odometry) and the point cloud with intensities (ekfvio_get_points)" if outputs else ""),
             "stage_us_per_frame": stage,
             "klt": {"pyramid_us": pyr_us, "track_us": trk_us, "tracks_per_s": (N / (trk_us * 1e-6)) if trk_us else None,
                     "pyramid_bytes": pyr_bytes,
@@ -411,10 +415,12 @@ def main():
         if world == 1 and not args.no_full_loop:
             try:
                 extra["full_loop"] = {"n64": full_loop(64, local), "n256": full_loop(256, local),
-                                      "node_defaults_n100_scale4": full_loop(100, local, node_defaults=True)}
+                                      "node_defaults_n100_scale4": full_loop(100, local, node_defaults=True),
+                                      "node_defaults_with_outputs": full_loop(100, local, node_defaults=True, outputs=True)}
                 extra["klt"] = extra["full_loop"]["n256"].pop("klt")
                 extra["full_loop"]["n64"].pop("klt")
                 extra["full_loop"]["node_defaults_n100_scale4"].pop("klt")
+                extra["full_loop"]["node_defaults_with_outputs"].pop("klt")
             except Exception as ex:  # reported, never fatal for the headline metric
                 extra["full_loop"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:

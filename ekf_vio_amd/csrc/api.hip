@@ -96,6 +96,19 @@ void add_features_enqueue_device_count(ekfvio_filter* f, const int* count_dev) {
                        f->last_klt, f->del_flag, f->zmeas, f->N, inv_depth, count_dev);
 }
 
+// one workgroup; publishes the status word itself once its own writes are out (see wait_status / poll_status)
+__global__ void copy_small_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, const int* __restrict__ info,
+                                  int* host_word, int seq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host_word[0] = info[0];
+        host_word[2] = 0;
+        __hip_atomic_store(host_word + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // The host's wait at the end of a frame.  A one-thread kernel behind everything else on the stream writes the status
 // word and a sequence number straight into pinned host memory; the host polls the sequence number.  Against a 4-byte
 // device-to-host copy plus hipStreamSynchronize this saves the copy's command and the interrupt-driven wake-up (≈10 us
@@ -109,6 +122,11 @@ __global__ void publish_status_kernel(const int* __restrict__ info, int* host_wo
 int wait_status(ekfvio_filter* f, int* status, const int* extra_dev, int* extra_out) {
     const int seq = ++f->status_seq;
     hipLaunchKernelGGL(publish_status_kernel, dim3(1), dim3(1), 0, f->stream, f->info, f->d_hinfo, seq, extra_dev);
+    return poll_status(f, seq, status, extra_out);
+}
+// The polling half: for a caller whose own last kernel publishes sequence number `seq` (from next_status_seq).
+int next_status_seq(ekfvio_filter* f) { return ++f->status_seq; }
+int poll_status(ekfvio_filter* f, int seq, int* status, int* extra_out) {
     HIPC(f, hipGetLastError());
     volatile int* hw = f->h_info;
     const auto t0 = std::chrono::steady_clock::now();
@@ -218,6 +236,11 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     memset(f->h_info, 0, 16 * sizeof(int));
     HIPC(f, hipHostGetDevicePointer((void**)&f->d_hinfo, f->h_info, 0));
     {
+        const size_t words = EKF_BASE + 4 * (size_t)(f->cfg.max_features > 0 ? f->cfg.max_features : 1);
+        HIPC(f, hipHostMalloc((void**)&f->h_out, words * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPC(f, hipHostGetDevicePointer((void**)&f->d_out, f->h_out, 0));
+    }
+    {
         const size_t cap = (size_t)(f->cfg.max_features > 0 ? f->cfg.max_features : 1);
         HIPC(f, hipHostMalloc((void**)&f->h_meas, 25 * cap, hipHostMallocDefault));
         HIPC(f, hipMalloc((void**)&f->d_meas, 25 * cap));
@@ -261,6 +284,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (f->h_info) hipHostFree(f->h_info);
+    if (f->h_out) hipHostFree(f->h_out);
     if (f->h_meas) hipHostFree(f->h_meas);
     if (f->d_meas) (void)hipFree(f->d_meas);
     klt_free(f);
@@ -372,8 +396,14 @@ int ekfvio_dim(const ekfvio_filter* f) { return f ? f->n : -1; }
 int ekfvio_get_base_mu(ekfvio_filter* f, float* base_mu) {
     if (!f || !base_mu) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
-    HIPC(f, hipMemcpyAsync(base_mu, f->mu, sizeof(float) * EKF_BASE, hipMemcpyDeviceToHost, f->stream));
-    HIPC(f, hipStreamSynchronize(f->stream));
+    // 22 floats: written by a kernel straight into pinned host memory and awaited like the status word (the node reads
+    // its odometry every frame: a device-to-host copy into pageable memory plus a synchronise cost three times as much)
+    const int seq = next_status_seq(f);
+    hipLaunchKernelGGL(copy_small_kernel, dim3(1), dim3(64), 0, f->stream, f->mu, f->d_out, EKF_BASE, f->info, f->d_hinfo, seq);
+    int bad = 0;
+    const int rc = poll_status(f, seq, &bad, nullptr);
+    if (rc != EKFVIO_OK) return rc;
+    memcpy(base_mu, f->h_out, sizeof(float) * EKF_BASE);
     return EKFVIO_OK;
 }
 

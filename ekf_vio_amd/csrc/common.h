@@ -115,6 +115,10 @@ struct ekfvio_filter {
     int* h_info = nullptr;     // pinned, device-mapped: [0] status word, [1] sequence number (publish_status_kernel)
     int* d_hinfo = nullptr;    // the device's address of h_info
     int status_seq = 0;
+    // small per-frame outputs (odometry, point cloud): kernels write them straight into pinned host memory and the host
+    // waits with wait_status: no device-to-host copy into pageable memory, no interrupt-driven synchronise
+    float* h_out = nullptr;    // pinned, device-mapped: EKF_BASE + 4 * max_features floats
+    float* d_out = nullptr;    // the device's address of h_out
     unsigned char* h_meas = nullptr;  // pinned staging for one frame's (z, R, pass): one H2D copy per ekfvio_update
     unsigned char* d_meas = nullptr;  // its device image: z at 0, R at 8N_cap, pass at 24N_cap bytes
     // uploaded measurement sequences
@@ -242,6 +246,9 @@ void fast_free(ekfvio_filter* f);
 // Waits for everything on the handle's stream and returns the factorisation's status word through *status (api.hip).
 // extra_dev (may be null): one more device word delivered with it through *extra_out.
 int wait_status(ekfvio_filter* f, int* status, const int* extra_dev = nullptr, int* extra_out = nullptr);
+// the same in two halves, for a caller whose own (single-workgroup) kernel publishes the words itself
+int next_status_seq(ekfvio_filter* f);
+int poll_status(ekfvio_filter* f, int seq, int* status, int* extra_out);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
 int add_features_device(ekfvio_filter* f, int k);
 void add_features_enqueue_device_count(ekfvio_filter* f, const int* count_dev);  // enqueue only; the caller updates N / n

@@ -678,10 +678,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, flo
 // at the landmark's pixel (Feature::getPixel: K(0)*mu(0) + K(2), K(4)*mu(1) + K(5); cv::Point2f -> cv::Point rounds
 // to nearest even, cvRound).  The reference reads outside the image unchecked; here such a landmark gets intensity 0.
 // img = pixel (0,0) of level 0 of the current frame, or null when no frame has been pushed (intensity 0 then).
-__global__ void points_kernel(const float* __restrict__ mu, int N, const uint8_t* __restrict__ img, int pitch, int w, int h,
-                              float fx, float fy, float cx, float cy, float* __restrict__ xyz, float* __restrict__ intensity) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+__device__ inline void points_one(const float* __restrict__ mu, int i, const uint8_t* __restrict__ img, int pitch, int w, int h,
+                                  float fx, float fy, float cx, float cy, float* __restrict__ xyz, float* __restrict__ intensity) {
     const float u = mu[EKF_BASE + 3 * i], v = mu[EKF_BASE + 3 * i + 1], rho = mu[EKF_BASE + 3 * i + 2];
     const float z = (float)(1.0 / (double)rho);
     xyz[3 * i] = u * z;
@@ -697,6 +695,22 @@ __global__ void points_kernel(const float* __restrict__ mu, int N, const uint8_t
         }
     }
     intensity[i] = in;
+}
+// host_word != nullptr (single-workgroup launches only): the kernel publishes the status word itself behind its writes
+__global__ void points_kernel(const float* __restrict__ mu, int N, const uint8_t* __restrict__ img, int pitch, int w, int h,
+                              float fx, float fy, float cx, float cy, float* __restrict__ xyz, float* __restrict__ intensity,
+                              const int* __restrict__ info, int* host_word, int seq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) points_one(mu, i, img, pitch, w, h, fx, fy, cx, cy, xyz, intensity);
+    if (host_word) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            host_word[0] = info[0];
+            host_word[2] = 0;
+            __hip_atomic_store(host_word + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) -------------------
@@ -1069,15 +1083,23 @@ int ekfvio_get_points(ekfvio_filter* f, float* xyz3N, float* intensityN) {
         h = fr.h[0];
         intrinsics(f, fr.K, &fx, &fy, &cx, &cy);
     }
-    // Rmeas (4 floats per landmark) is free between updates: xyz in its first 3N floats, the intensities behind them
-    float* d_xyz = f->Rmeas;
-    float* d_int = f->Rmeas + 3 * (size_t)N;
-    hipLaunchKernelGGL(points_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->mu, N, img, pitch, w, h, fx, fy, cx, cy,
-                       d_xyz, d_int);
-    if (xyz3N) HIPK(f, hipMemcpyAsync(xyz3N, d_xyz, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, f->stream));
-    if (intensityN) HIPK(f, hipMemcpyAsync(intensityN, d_int, sizeof(float) * N, hipMemcpyDeviceToHost, f->stream));
-    HIPK(f, hipGetLastError());
-    HIPK(f, hipStreamSynchronize(f->stream));
+    // the kernel writes into pinned host memory (behind the 22 floats ekfvio_get_base_mu uses): xyz, then the intensities
+    float* d_xyz = f->d_out + EKF_BASE;
+    float* d_int = d_xyz + 3 * (size_t)N;
+    int bad = 0, rc;
+    if (N <= 256) {  // one workgroup: it publishes the status word itself
+        const int seq = next_status_seq(f);
+        hipLaunchKernelGGL(points_kernel, dim3(1), dim3(256), 0, f->stream, f->mu, N, img, pitch, w, h, fx, fy, cx, cy, d_xyz, d_int,
+                           f->info, f->d_hinfo, seq);
+        rc = poll_status(f, seq, &bad, nullptr);
+    } else {
+        hipLaunchKernelGGL(points_kernel, dim3((N + 255) / 256), dim3(256), 0, f->stream, f->mu, N, img, pitch, w, h, fx, fy, cx, cy,
+                           d_xyz, d_int, nullptr, nullptr, 0);
+        rc = wait_status(f, &bad);
+    }
+    if (rc != EKFVIO_OK) return rc;
+    if (xyz3N) memcpy(xyz3N, f->h_out + EKF_BASE, sizeof(float) * 3 * N);
+    if (intensityN) memcpy(intensityN, f->h_out + EKF_BASE + 3 * (size_t)N, sizeof(float) * N);
     return EKFVIO_OK;
 }
 
