@@ -147,14 +147,14 @@ __global__ __launch_bounds__(FAST_CHUNK) void fast_rows_kernel(const uint8_t* __
     __syncthreads();
     if (tid == 0) row_cnt[y] = s_base;
 }
-__global__ __launch_bounds__(1024) void fast_gather_kernel(const unsigned* __restrict__ row_kp, const int* __restrict__ row_cnt, int w, int h,
-                                                           int cap, int* __restrict__ kp_xy, short* __restrict__ kp_score, int* total) {
-    __shared__ int s_w[16];
-    __shared__ int s_carry;
+// the row lists copied, in row order, into the keypoint arrays; NT threads of one workgroup
+template <int NT>
+__device__ inline void fast_gather_body(const unsigned* __restrict__ row_kp, const int* __restrict__ row_cnt, int w, int h, int cap,
+                                        int* __restrict__ kp_xy, short* __restrict__ kp_score, int* total, int* s_w, int* s_carry) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    if (tid == 0) *s_carry = 0;
     __syncthreads();
-    for (int y0 = 0; y0 < h; y0 += 1024) {
+    for (int y0 = 0; y0 < h; y0 += NT) {
         const int y = y0 + tid;
         const int c = (y < h) ? row_cnt[y] : 0;
         int incl = c;
@@ -167,11 +167,11 @@ __global__ __launch_bounds__(1024) void fast_gather_kernel(const unsigned* __res
         __syncthreads();
         int before = 0, tot = 0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
+        for (int q = 0; q < NT / 64; q++) {
             before += (q < wv) ? s_w[q] : 0;
             tot += s_w[q];
         }
-        const int carry = s_carry;
+        const int carry = *s_carry;
         const int off0 = carry + before + incl - c;  // this row's first slot
         const unsigned* src = row_kp + (size_t)y * w;
         for (int i = 0; i < c; i++) {
@@ -184,10 +184,16 @@ __global__ __launch_bounds__(1024) void fast_gather_kernel(const unsigned* __res
             }
         }
         __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
+        if (tid == 0) *s_carry = carry + tot;
         __syncthreads();
     }
-    if (tid == 0) *total = s_carry;
+    if (tid == 0) *total = *s_carry;
+}
+__global__ __launch_bounds__(1024) void fast_gather_kernel(const unsigned* __restrict__ row_kp, const int* __restrict__ row_cnt, int w, int h,
+                                                           int cap, int* __restrict__ kp_xy, short* __restrict__ kp_score, int* total) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    fast_gather_body<1024>(row_kp, row_cnt, w, h, cap, kp_xy, kp_score, total, s_w, &s_carry);
 }
 
 // drawing.cpp Circle(), filled: half-width of the span in row cy + dyrow (-1: the row is outside the circle)
@@ -254,11 +260,24 @@ __device__ inline void stamp_circle(const OccMask<LDSMASK>& mask, int w, int h, 
 // bit ORs; every wavefront fetches 64 landmark pixels at once and takes every fourth); the first fit itself is sequential
 // by definition and stays with wavefront 0.  The global mask (LDSMASK = false) is zeroed by the caller.
 template <bool LDSMASK>
-__global__ __launch_bounds__(256) void replenish_select_kernel(const int* __restrict__ kp_xy, const int* __restrict__ kp_count, int cap_kp,
+__global__ __launch_bounds__(256) void replenish_select_kernel(const int* kp_xy, const int* kp_count, int cap_kp,
                                                               const float* __restrict__ mu, int N_old, float fx, float fy, float cx,
                                                               float cy, int num_features, int w, int h, int radius, int kill_pad,
-                                                              unsigned* gmask, int* new_xy, float* new_uv, int* new_count) {
+                                                              unsigned* gmask, int* new_xy, float* new_uv, int* new_count,
+                                                              const unsigned* __restrict__ row_kp, const int* __restrict__ row_cnt,
+                                                              int* kp_xy_out, short* kp_score_out, int* kp_total_out) {
     __shared__ unsigned lmask[LDSMASK ? OCC_LDS_WORDS : 1];
+    __shared__ int s_gw[4];
+    __shared__ int s_gcarry;
+    // row_kp != nullptr: the detector's row lists are flattened here, by the same four wavefronts that prepare the mask
+    // (fast_gather_kernel's launch saved); kp_xy / kp_count then alias the arrays written here
+    if (row_kp) {
+        fast_gather_body<256>(row_kp, row_cnt, w, h, cap_kp, kp_xy_out, kp_score_out, kp_total_out, s_gw, &s_gcarry);
+        __threadfence();
+        __syncthreads();
+        kp_xy = kp_xy_out;
+        kp_count = kp_total_out;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     OccMask<LDSMASK> mask;
     mask.wpr = (w + 31) / 32;
@@ -390,7 +409,8 @@ void fast_free(ekfvio_filter* f) {
 }
 
 // cv::FAST on level 0 of the current frame -> f->fast_kp_* (raster order), count in f->fast_counts[0]
-int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur) {
+// gather = false: the row lists are left for the caller's own kernel to flatten (replenish_select_kernel)
+int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur, bool gather = true) {
     const KltFrame& fr = f->frames[f->cur];
     if (!fr.valid) {
         f->last_error = "FAST needs a frame";
@@ -409,8 +429,9 @@ int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur) {
     }
     hipLaunchKernelGGL(fast_rows_kernel, dim3(h), dim3(FAST_CHUNK), 0, f->stream, img0, w, h, pitch, threshold, nonmax, f->fast_row_kp,
                        f->fast_row_cnt);
-    hipLaunchKernelGGL(fast_gather_kernel, dim3(1), dim3(1024), 0, f->stream, f->fast_row_kp, f->fast_row_cnt, w, h, f->fast_kp_cap,
-                       f->fast_kp_xy, f->fast_kp_score, f->fast_counts);
+    if (gather)
+        hipLaunchKernelGGL(fast_gather_kernel, dim3(1), dim3(1024), 0, f->stream, f->fast_row_kp, f->fast_row_cnt, w, h, f->fast_kp_cap,
+                           f->fast_kp_xy, f->fast_kp_score, f->fast_counts);
     return EKFVIO_OK;
 }
 
@@ -429,7 +450,7 @@ int replenish_enqueue(ekfvio_filter* f, int* enqueued) {
     }
     HIPF(f, hipSetDevice(f->device));
     if (f->N >= f->cfg.max_features) return EKFVIO_OK;  // "if (tc_ekf.features.size() < NUM_FEATURES)" (:236)
-    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1, f->cfg.fast_blur_sigma != 0.f);
+    int rc = fast_detect_device(f, f->cfg.fast_threshold, 1, f->cfg.fast_blur_sigma != 0.f, false);
     if (rc != EKFVIO_OK) return rc;
     const KltFrame& fr = f->frames[f->cur];
     const int w = fr.w[0], h = fr.h[0];
@@ -439,12 +460,14 @@ int replenish_enqueue(ekfvio_filter* f, int* enqueued) {
     if (mask_words <= OCC_LDS_WORDS) {
         hipLaunchKernelGGL(replenish_select_kernel<true>, dim3(1), dim3(256), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
                            f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
-                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
+                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1, f->fast_row_kp, f->fast_row_cnt, f->fast_kp_xy,
+                           f->fast_kp_score, f->fast_counts);
     } else {
         HIPF(f, hipMemsetAsync(f->occ_mask, 0, mask_words * sizeof(unsigned), f->stream));
         hipLaunchKernelGGL(replenish_select_kernel<false>, dim3(1), dim3(256), 0, f->stream, f->fast_kp_xy, f->fast_counts, f->fast_kp_cap,
                            f->mu, f->N, fx, fy, cx, cy, f->cfg.max_features, w, h, f->cfg.min_new_feature_dist, f->cfg.kill_pad,
-                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1);
+                           (unsigned*)f->occ_mask, f->new_xy, f->zmeas, f->fast_counts + 1, f->fast_row_kp, f->fast_row_cnt, f->fast_kp_xy,
+                           f->fast_kp_score, f->fast_counts);
     }
     *enqueued = 1;
     return EKFVIO_OK;
