@@ -53,6 +53,7 @@ struct KltFrame {
     int levels = 0;  // number of valid levels (maxLevel+1)
     float K[9] = {0};
     bool valid = false;
+    int cap_w = 0, cap_h = 0;  // level-0 size the planes were allocated for (they grow with the first larger frame)
 };
 
 struct ekfvio_filter {
@@ -140,6 +141,7 @@ struct ekfvio_filter {
     float* klt_cov_px = nullptr;   // [4*max_features] sample-based pixel covariances (cfg.sample_based_uncertainty)
     uint8_t* staging = nullptr;    // device staging for the uploaded image
     uint8_t* h_image = nullptr;    // pinned host staging: the caller's frame is copied here, so its buffer is free on return without a stream sync
+    size_t src_cap = 0;            // bytes of staging / h_image (the uploaded, un-resized frame)
     // --- frame ingest + replenishment (fast.hip) ---
     uint8_t* blurred = nullptr;    // replenishFeatures' cv::GaussianBlur output (only with cfg.fast_blur_sigma != 0)
     unsigned* fast_row_kp = nullptr;  // [w*h] per image row its keypoints in x order, (score << 16) | x
@@ -150,6 +152,7 @@ struct ekfvio_filter {
     int* fast_row_cnt = nullptr;   // [max_image_height] keypoints per row
     int* new_xy = nullptr;         // pixels of the landmarks added by the last replenishment
     int* fast_counts = nullptr;    // [0] keypoints found, [1] landmarks added
+    int fast_cap_w = 0, fast_cap_h = 0;  // level-0 size the detector's buffers were allocated for
     double t_stamp = 0;
     bool have_stamp = false;
 
@@ -243,6 +246,7 @@ void launch_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[
 // fast.hip
 int fast_alloc(ekfvio_filter* f);
 void fast_free(ekfvio_filter* f);
+int fast_ensure(ekfvio_filter* f, int w, int h);  // grows the detector's per-pixel buffers to a w x h level 0 (synchronises if it must)
 // Waits for everything on the handle's stream and returns the factorisation's status word through *status (api.hip).
 // extra_dev (may be null): one more device word delivered with it through *extra_out.
 int wait_status(ekfvio_filter* f, int* status, const int* extra_dev = nullptr, int* extra_out = nullptr);

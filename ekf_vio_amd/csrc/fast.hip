@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void replenish_select_kernel(const int* kp_xy,
     }
     if (!LDSMASK) __threadfence();  // the other wavefronts' ORs went to the global mask
     __syncthreads();
-    if (wave != 0) return;  // (the barriers below are wavefront 0's alone from here on)
+    if (wave != 0) return;  // (no workgroup barrier below this line)
     int wanted = num_features - N_old, added = 0;
     const int nk = min(*kp_count, cap_kp);
     for (int c0 = 0; c0 < nk && added < wanted; c0 += 64) {
@@ -331,7 +331,10 @@ __global__ __launch_bounds__(256) void replenish_select_kernel(const int* kp_xy,
             }
             added++;
             stamp_circle(mask, w, h, ax, ay, radius, lane, hw);
-            __syncthreads();
+            // this wavefront's own ORs must have landed before it tests the mask again; wavefronts 1-3 have exited, so
+            // a workgroup barrier here would be a barrier after a partial exit: wait for the wave's own memory operations
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
             todo &= ~((2ull << L) - 1ull);  // everything up to and including L is consumed
         }
     }
@@ -386,20 +389,48 @@ static void gauss5_taps(float sigma, int k[5]) {
     }
 }
 
-int fast_alloc(ekfvio_filter* f) {
+// The detector's per-pixel buffers for a level 0 of up to w x h pixels.  Frame::Frame takes any image (Frame.cpp:15-42):
+// the buffers start at cfg.max_image_width x max_image_height and grow with the first frame that needs more.
+int fast_ensure(ekfvio_filter* f, int w, int h) {
+    if (w <= f->fast_cap_w && h <= f->fast_cap_h) return EKFVIO_OK;
     const ekfvio_config& c = f->cfg;
-    const size_t px = (size_t)c.max_image_width * c.max_image_height;
+    w = std::max(w, f->fast_cap_w);
+    h = std::max(h, f->fast_cap_h);
+    if (f->stream) HIPF(f, hipStreamSynchronize(f->stream));  // nothing in flight may still read the old buffers
+    void* old[] = {f->blurred, f->fast_row_kp, f->fast_kp_xy, f->fast_kp_score, f->occ_mask, f->fast_row_cnt};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    f->blurred = nullptr, f->fast_row_kp = nullptr, f->fast_kp_xy = nullptr, f->fast_kp_score = nullptr, f->occ_mask = nullptr,
+    f->fast_row_cnt = nullptr;
+    f->fast_cap_w = f->fast_cap_h = 0;
+    const size_t px = (size_t)w * h;
     if (c.fast_blur_sigma != 0.f) HIPF(f, hipMalloc((void**)&f->blurred, px));
     HIPF(f, hipMalloc((void**)&f->fast_row_kp, px * sizeof(unsigned)));  // per image row: its keypoints in x order, (score << 16) | x
     f->fast_kp_cap = (int)(px / 4 + 1);
     HIPF(f, hipMalloc((void**)&f->fast_kp_xy, (size_t)f->fast_kp_cap * 2 * sizeof(int)));
     HIPF(f, hipMalloc((void**)&f->fast_kp_score, (size_t)f->fast_kp_cap * sizeof(short)));
-    HIPF(f, hipMalloc((void**)&f->occ_mask, ((size_t)(c.max_image_width + 31) / 32) * c.max_image_height * sizeof(unsigned)));
-    HIPF(f, hipMalloc((void**)&f->fast_row_cnt, (size_t)c.max_image_height * sizeof(int)));
+    HIPF(f, hipMalloc((void**)&f->occ_mask, ((size_t)(w + 31) / 32) * h * sizeof(unsigned)));
+    HIPF(f, hipMalloc((void**)&f->fast_row_cnt, (size_t)h * sizeof(int)));
+    f->fast_cap_w = w;
+    f->fast_cap_h = h;
+    return EKFVIO_OK;
+}
+
+int fast_alloc(ekfvio_filter* f) {
+    const ekfvio_config& c = f->cfg;
+    // what replenishFeatures can be asked for is checked here, once, not in the middle of a frame
+    if (c.fast_blur_sigma != 0.f && !(c.fast_blur_sigma > 0.f)) {
+        f->last_error = "fast_blur_sigma must be >= 0";  // cv::GaussianBlur would derive sigma from the kernel size
+        return EKFVIO_EINVAL;
+    }
+    if (c.min_new_feature_dist < 0 || c.min_new_feature_dist > 64 * OCC_PASSES / 2 - 1) {
+        f->last_error = "min_new_feature_dist must be in [0, 63]";
+        return EKFVIO_EINVAL;
+    }
     const int maxf = c.max_features > 0 ? c.max_features : 1;
     HIPF(f, hipMalloc((void**)&f->new_xy, (size_t)maxf * 2 * sizeof(int)));
     HIPF(f, hipMalloc((void**)&f->fast_counts, 4 * sizeof(int)));
-    return EKFVIO_OK;
+    return fast_ensure(f, c.max_image_width, c.max_image_height);
 }
 
 void fast_free(ekfvio_filter* f) {
@@ -440,14 +471,7 @@ int fast_detect_device(ekfvio_filter* f, int threshold, int nonmax, bool blur, b
 int replenish_enqueue(ekfvio_filter* f, int* enqueued) {
     *enqueued = 0;
     if (!f) return EKFVIO_EINVAL;
-    if (f->cfg.fast_blur_sigma != 0.f && !(f->cfg.fast_blur_sigma > 0.f)) {
-        f->last_error = "fast_blur_sigma must be >= 0";  // cv::GaussianBlur would derive sigma from the kernel size
-        return EKFVIO_EINVAL;
-    }
-    if (f->cfg.min_new_feature_dist < 0 || f->cfg.min_new_feature_dist > 64 * OCC_PASSES / 2 - 1) {
-        f->last_error = "min_new_feature_dist must be in [0, 63]";
-        return EKFVIO_EINVAL;
-    }
+    // (fast_blur_sigma and min_new_feature_dist were validated by ekfvio_create: fast_alloc)
     HIPF(f, hipSetDevice(f->device));
     if (f->N >= f->cfg.max_features) return EKFVIO_OK;  // "if (tc_ekf.features.size() < NUM_FEATURES)" (:236)
     int rc = fast_detect_device(f, f->cfg.fast_threshold, 1, f->cfg.fast_blur_sigma != 0.f, false);

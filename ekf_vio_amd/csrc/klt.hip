@@ -857,6 +857,57 @@ int klt_level_pitch(int w) { return level_pitch(w); }
 int klt_border() { return KLT_BORDER; }
 void klt_intrinsics(const ekfvio_filter* f, const float* K, float* fx, float* fy, float* cx, float* cy);
 
+// Planes of one frame for a level 0 of up to w x h pixels (every level the configuration allows).
+static int frame_planes_alloc(ekfvio_filter* f, KltFrame& fr, int w, int h) {
+    for (int l = 0; l < 8; l++) {
+        if (fr.img[l]) (void)hipFree(fr.img[l]);
+        if (fr.deriv[l]) (void)hipFree(fr.deriv[l]);
+        fr.img[l] = nullptr;
+        fr.deriv[l] = nullptr;
+    }
+    fr.cap_w = fr.cap_h = 0;
+    fr.valid = false;
+    int lw = w, lh = h;
+    for (int l = 0; l <= f->cfg.klt_max_pyramid_level; l++) {
+        // + one row of slack: the tracker's aligned 4-byte loads may touch up to 3 bytes past a row's last pixel
+        const size_t px = (size_t)level_pitch(lw) * (lh + 2 * KLT_BORDER + 1);
+        HIPK(f, hipMalloc((void**)&fr.img[l], px));
+        HIPK(f, hipMalloc((void**)&fr.deriv[l], px * 2 * sizeof(short)));
+        HIPK(f, hipMemsetAsync(fr.img[l], 0, px, f->stream));
+        HIPK(f, hipMemsetAsync(fr.deriv[l], 0, px * 2 * sizeof(short), f->stream));
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+    }
+    fr.cap_w = w;
+    fr.cap_h = h;
+    return EKFVIO_OK;
+}
+
+// Frame::Frame takes any image (Frame.cpp:15-42): cfg.max_image_width x max_image_height is only what is allocated up
+// front.  A frame that needs more grows the upload staging, the planes of the frame slot it will be written to (the
+// other slot, the previous frame, keeps its planes and its contents) and the detector's buffers; this synchronises the
+// stream and allocates, once per size.
+static int ensure_frame_capacity(ekfvio_filter* f, int sw, int sh, int w, int h) {
+    const size_t src = (size_t)sw * sh;
+    KltFrame& fr = f->frames[f->cur ^ 1];
+    if (src <= f->src_cap && w <= fr.cap_w && h <= fr.cap_h && w <= f->fast_cap_w && h <= f->fast_cap_h) return EKFVIO_OK;
+    HIPK(f, hipSetDevice(f->device));
+    HIPK(f, hipStreamSynchronize(f->stream));
+    if (src > f->src_cap) {
+        if (f->staging) (void)hipFree(f->staging);
+        if (f->h_image) (void)hipHostFree(f->h_image);
+        f->staging = nullptr, f->h_image = nullptr, f->src_cap = 0;
+        HIPK(f, hipMalloc((void**)&f->staging, src));
+        HIPK(f, hipHostMalloc((void**)&f->h_image, src, hipHostMallocDefault));
+        f->src_cap = src;
+    }
+    if (w > fr.cap_w || h > fr.cap_h) {
+        const int rc = frame_planes_alloc(f, fr, std::max(w, fr.cap_w), std::max(h, fr.cap_h));
+        if (rc != EKFVIO_OK) return rc;
+    }
+    return fast_ensure(f, w, h);
+}
+
 int klt_alloc(ekfvio_filter* f) {
     const ekfvio_config& c = f->cfg;
     if (c.klt_window_size < 3 || c.klt_window_size > KLT_MAX_WIN || (c.klt_window_size & 1) == 0 ||
@@ -865,25 +916,17 @@ int klt_alloc(ekfvio_filter* f) {
         return EKFVIO_EINVAL;
     }
     for (int fr = 0; fr < 2; fr++) {
-        int w = c.max_image_width, h = c.max_image_height;
-        for (int l = 0; l <= c.klt_max_pyramid_level; l++) {
-            // + one row of slack: the tracker's aligned 4-byte loads may touch up to 3 bytes past a row's last pixel
-            const size_t px = (size_t)level_pitch(w) * (h + 2 * KLT_BORDER + 1);
-            HIPK(f, hipMalloc((void**)&f->frames[fr].img[l], px));
-            HIPK(f, hipMalloc((void**)&f->frames[fr].deriv[l], px * 2 * sizeof(short)));
-            HIPK(f, hipMemsetAsync(f->frames[fr].img[l], 0, px, f->stream));
-            HIPK(f, hipMemsetAsync(f->frames[fr].deriv[l], 0, px * 2 * sizeof(short), f->stream));
-            w = (w + 1) / 2;
-            h = (h + 1) / 2;
-        }
+        const int rc = frame_planes_alloc(f, f->frames[fr], c.max_image_width, c.max_image_height);
+        if (rc != EKFVIO_OK) return rc;
     }
     const size_t maxf = f->cfg.max_features > 0 ? f->cfg.max_features : 1;
     HIPK(f, hipMalloc((void**)&f->klt_prev_px, sizeof(float) * 2 * maxf));
     HIPK(f, hipMalloc((void**)&f->klt_next_px, sizeof(float) * 2 * maxf));
     HIPK(f, hipMalloc((void**)&f->klt_status, maxf));
     HIPK(f, hipMalloc((void**)&f->klt_cov_px, sizeof(float) * 4 * maxf));
-    HIPK(f, hipMalloc((void**)&f->staging, (size_t)c.max_image_width * c.max_image_height));
-    HIPK(f, hipHostMalloc((void**)&f->h_image, (size_t)c.max_image_width * c.max_image_height, hipHostMallocDefault));
+    f->src_cap = (size_t)c.max_image_width * c.max_image_height;
+    HIPK(f, hipMalloc((void**)&f->staging, f->src_cap));
+    HIPK(f, hipHostMalloc((void**)&f->h_image, f->src_cap, hipHostMallocDefault));
     return EKFVIO_OK;
 }
 
@@ -1016,13 +1059,13 @@ int klt_track_device(ekfvio_filter* f) {
 // (Measured and dropped: the upload and the pyramid on a stream of their own beside process(dt), joined by an event in
 // front of the tracker.  The two cross-stream waits cost more than the 12 us of overlap they buy: 161 instead of 141 us
 // per frame at N = 64.)
-static int push_frame_check(const ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+static int push_frame_check(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                             const float K[9]) {
     if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
-    if (width > f->cfg.max_image_width || height > f->cfg.max_image_height) return EKFVIO_ECAPACITY;
+    if (width > 16384 || height > 16384) return EKFVIO_ECAPACITY;  // keypoints carry x in 16 bits (fast.hip)
     const int s = f->cfg.inverse_image_scale > 1 ? f->cfg.inverse_image_scale : 1;
     if (width / s < 1 || height / s < 1) return EKFVIO_EINVAL;
-    return EKFVIO_OK;
+    return ensure_frame_capacity(f, width, height, width / s, height / s);
 }
 static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                               const float K[9]) {
@@ -1202,15 +1245,24 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
     // nothing below waits for the device until the status word is read at the very end: process(dt), the frame
     // upload, the pyramid, the tracker and the update are enqueued back to back.  process(dt) goes first: it does not
     // depend on the image, so the device runs it while the host copies the frame into the pinned buffer.
+    // everything that can refuse the frame (sizes, capacity growth) comes before the first launch
     int rc = push_frame_check(f, image, width, height, stride, K);
     if (rc != EKFVIO_OK) return rc;
     const float dt = first ? 0.f : (float)(stamp - f->t_stamp);
+    // an error return from here on has work enqueued behind it: wait for it (the pinned frame buffer is rewritten by the
+    // next call) and leave the stamp with the state it belongs to
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(f->stream);
+        return code;
+    };
     if (!first) {
         HIPK(f, hipSetDevice(f->device));
         launch_predict(f, dt);
+        f->t_stamp = stamp;  // tc_ekf.t = f.t (:164): the state now stands at this stamp whatever happens below
+        f->have_stamp = true;
     }
     rc = push_frame_enqueue(f, image, width, height, stride, K);
-    if (rc != EKFVIO_OK) return rc;
+    if (rc != EKFVIO_OK) return fail(rc);
     if (first) {
         // first frame: remember the stamp (tc_ekf.t = f.t) and return; the caller replenishes
         if (!f->have_stamp) {
@@ -1221,24 +1273,25 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         HIPK(f, hipStreamSynchronize(f->stream));
         return EKFVIO_OK;
     }
-    f->t_stamp = stamp;
-    f->have_stamp = true;
     int status = EKFVIO_OK;
     if (f->N > 0) {  // "run update if we have enough features" (EKFVIO.cpp:166)
         rc = klt_track_device(f);
-        if (rc != EKFVIO_OK) return rc;
+        if (rc != EKFVIO_OK) return fail(rc);
         // the pass flags stay on the device: the update is launched for m = 2N measurement rows and its kernels take
         // the true count from the bookkeeping (rows beyond it are identity padding, exact zeros in every product)
         launch_update(f, 0, f->zmeas, f->Rmeas, f->pass, nullptr, 0, false, true);
     }
-    HIPK(f, hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        f->last_error = "launch failed in ekfvio_step_image";
+        return fail(EKFVIO_EDEVICE);
+    }
     // "try to get more features if needed" (:172): detection, first-fit selection and the growth of the state are
     // enqueued behind the update with the number of new landmarks left on the device; the host reads it with the status
     // word, in the frame's single wait, and only then counts the landmarks in
     int replenishing = 0;
     if (f->cfg.replenish) {
         rc = replenish_enqueue(f, &replenishing);
-        if (rc != EKFVIO_OK) return rc;
+        if (rc != EKFVIO_OK) return fail(rc);
         if (replenishing) add_features_enqueue_device_count(f, f->fast_counts + 1);
     }
     int bad = 0, added = 0;

@@ -321,13 +321,21 @@ class EKFVIO:
     def __init__(self, **kw):
         self.tc_ekf = TightlyCoupledEKF(**kw)
         self.tracker = KLTTracker(self.tc_ekf)
+        self._imu_queue = []      # (stamp, gyro, accel), kept in stamp order; only used with use_imu = 1
+        self._t_filter = None     # the stamp the device state stands at
+        self._last_K = None
+        self.dropped_imu = 0
 
     def addFrame(self, stamp, img, K):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         h, w = img.shape
         K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
-        return self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_step_image(self.tc_ekf.h, float(stamp), _u8(img), w, h, w, _fp(K)),
-                                allow=(capi.ENUMERIC,))
+        self._drain_imu(float(stamp))  # IMU records up to this frame's stamp, in stamp order, before the frame itself
+        rc = self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_step_image(self.tc_ekf.h, float(stamp), _u8(img), w, h, w, _fp(K)),
+                              allow=(capi.ENUMERIC,))
+        self._t_filter = float(stamp) if self._t_filter is None else max(self._t_filter, float(stamp))
+        self._last_K = K.copy()
+        return rc
 
     def replenishFeatures(self):
         """EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame, on the device: FAST-9/16 with
@@ -350,10 +358,61 @@ class EKFVIO:
 
     def imu_callback(self, stamp, gyro, accel):
         """EKFVIO::imu_callback (EKFVIO.cpp:113-115): a logging stub in the reference, and a no-op here unless the filter was
-        created with use_imu=1 (then: propagate to `stamp`, IMU measurement update)."""
+        created with use_imu=1.  Then the record is queued and applied (propagate to its stamp, IMU measurement update) in
+        stamp order in front of the next frame whose stamp is not older: IMU messages stamped after an image reach a node
+        before that image does.  A record older than the filter's time is dropped and counted (`dropped_imu`)."""
+        g = np.ascontiguousarray(gyro, dtype=np.float32)
+        a = np.ascontiguousarray(accel, dtype=np.float32)
+        if not self.tc_ekf.cfg.use_imu:
+            self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_imu(self.tc_ekf.h, float(stamp), _fp(g), _fp(a)))
+            return
+        stamp = float(stamp)
+        if self._t_filter is not None and stamp < self._t_filter:
+            self.dropped_imu += 1
+            return
+        i = len(self._imu_queue)
+        while i > 0 and self._imu_queue[i - 1][0] > stamp:
+            i -= 1
+        self._imu_queue.insert(i, (stamp, g, a))
+        if len(self._imu_queue) > 1000:  # the reference's subscriber queue (EKFVIO.cpp:80)
+            self._imu_queue.pop(0)
+            self.dropped_imu += 1
+
+    def imu_now(self, stamp, gyro, accel):
+        """ekfvio_imu directly, for a caller that delivers records in stamp order itself (EKFVIO_EINVAL for an older one)."""
         g = np.ascontiguousarray(gyro, dtype=np.float32)
         a = np.ascontiguousarray(accel, dtype=np.float32)
         self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_imu(self.tc_ekf.h, float(stamp), _fp(g), _fp(a)))
+        self._t_filter = float(stamp)
+
+    def _drain_imu(self, until):
+        while self._imu_queue and self._imu_queue[0][0] <= until:
+            stamp, g, a = self._imu_queue.pop(0)
+            if self._t_filter is not None and stamp < self._t_filter:
+                self.dropped_imu += 1
+                continue
+            self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_imu(self.tc_ekf.h, stamp, _fp(g), _fp(a)))
+            self._t_filter = stamp
+
+    def insight(self):
+        """publishInsight's image (EKFVIO.cpp:379-442): the resized frame as BGR8 [h, w, 3] with a green 22-pixel square
+        (cv::drawMarker MARKER_SQUARE) at the pixel of every landmark that is not flagged for deletion."""
+        grey, _ = self.tracker.level(0)
+        h, w = grey.shape
+        out = np.repeat(grey[:, :, None], 3, axis=2).copy()
+        s = max(int(self.tc_ekf.cfg.inverse_image_scale), 1)
+        fx = np.float32(np.float64(self._last_K[0]) / s)
+        fy = np.float32(np.float64(self._last_K[4]) / s)
+        st = self.tc_ekf.get_state()
+        for (u, v, _), flag in zip(st["feat_mu"], st["del_flag"]):
+            if flag:
+                continue
+            px, py = int(np.rint(np.float32(u) * fx)), int(np.rint(np.float32(v) * fy))
+            for d in range(-11, 12):
+                for x, y in ((px + d, py - 11), (px + d, py + 11), (px - 11, py + d), (px + 11, py + d)):
+                    if 0 <= x < w and 0 <= y < h:
+                        out[y, x] = (0, 255, 0)
+        return out
 
     def odometry(self):
         """What publishOdometry sends (EKFVIO.cpp:444-477): position, orientation (w,x,y,z), twist."""

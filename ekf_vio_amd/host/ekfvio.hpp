@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <deque>
 #include <fstream>
 #include <map>
 #include <stdexcept>
@@ -318,13 +319,28 @@ struct PointCloud {
     std::vector<float> intensity;   // image byte at the landmark's pixel
 };
 
+// publishInsight's payload (EKFVIO.cpp:379-442): the RESIZED frame as BGR8 with a green 22-pixel square marker
+// (cv::drawMarker(..., MARKER_SQUARE, 22, 1)) at the pixel of every landmark that is not flagged for deletion, and the
+// CameraInfo numbers the reference fills in (its K/P entries come from linear indexing of a column-major Matrix3f:
+// K is published transposed, P(0,2) and P(1,2) are the zero entries K(2,0), K(2,1); reproduced as they are).
+struct Insight {
+    double stamp = 0;
+    int width = 0, height = 0;
+    std::vector<uint8_t> bgr;  // height x width x 3
+    std::array<double, 9> K{};
+    std::array<double, 12> P{};
+};
+
 // The step sequence of EKFVIO::addFrame (EKFVIO.cpp:139-196) with the ROS plumbing removed.
 class EKFVIO {
    public:
     explicit EKFVIO(int max_features = 100, int device = 0, const ekfvio_config* cfg = nullptr)
-        : tc_ekf(max_features, device, cfg), tracker(tc_ekf) {}
+        : tc_ekf(max_features, device, cfg), tracker(tc_ekf), use_imu_(cfg ? cfg->use_imu != 0 : false),
+          scale_(cfg && cfg->inverse_image_scale > 1 ? cfg->inverse_image_scale : 1) {}
     // the node's constructor (EKFVIO.cpp:19-67): parameters by the reference's names (see Params)
-    explicit EKFVIO(const Params& p, int device = 0) : tc_ekf(p.cfg.max_features, device, &p.cfg), tracker(tc_ekf), params(p.node) {}
+    explicit EKFVIO(const Params& p, int device = 0)
+        : tc_ekf(p.cfg.max_features, device, &p.cfg), tracker(tc_ekf), params(p.node), use_imu_(p.cfg.use_imu != 0),
+          scale_(p.cfg.inverse_image_scale > 1 ? p.cfg.inverse_image_scale : 1) {}
     TightlyCoupledEKF tc_ekf;
     KLTTracker tracker;
     std::map<std::string, std::string> params;  // node-level parameters (topics, frames, switches) for the ROS side
@@ -342,8 +358,14 @@ class EKFVIO {
 
     // returns false on a numeric warning (see updateWithFeaturePositions)
     bool addFrame(const Frame& f) {
+        drainImu(f.t);  // IMU records up to this frame's stamp, in stamp order, before the frame itself
         int rc = ekfvio_step_image(tc_ekf.handle(), f.t, f.img, f.cols, f.rows, f.step, f.K.data());
-        last_stamp_ = f.t;
+        if (rc == EKFVIO_OK || rc == EKFVIO_ENUMERIC) {
+            last_stamp_ = f.t;
+            if (!have_time_ || f.t > t_filter_) t_filter_ = f.t;
+            have_time_ = true;
+            for (int i = 0; i < 9; i++) last_K_[i] = f.K[i];
+        }
         if (rc == EKFVIO_ENUMERIC) return false;
         tc_ekf.chk(rc);
         return true;
@@ -364,12 +386,96 @@ class EKFVIO {
         tc_ekf.chk(ekfvio_get_points(tc_ekf.handle(), N ? c.points[0].data() : nullptr, N ? c.intensity.data() : nullptr));
         return c;
     }
-    void imu_callback(double stamp, const Vector3f& gyro, const Vector3f& accel) {
-        tc_ekf.chk(ekfvio_imu(tc_ekf.handle(), stamp, gyro.data(), accel.data()));
+    // what publishInsight(cf) sends (EKFVIO.cpp:379-442); needs a frame
+    Insight insight() {
+        Insight o;
+        o.stamp = last_stamp_;
+        int32_t w = 0, h = 0;
+        tc_ekf.chk(ekfvio_klt_get_level(tc_ekf.handle(), 0, &w, &h, nullptr, nullptr));
+        std::vector<uint8_t> grey((size_t)w * h);
+        tc_ekf.chk(ekfvio_klt_get_level(tc_ekf.handle(), 0, &w, &h, grey.data(), nullptr));
+        o.width = w;
+        o.height = h;
+        o.bgr.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < grey.size(); i++) o.bgr[3 * i] = o.bgr[3 * i + 1] = o.bgr[3 * i + 2] = grey[i];  // CV_GRAY2BGR
+        // Frame::Frame's K (Frame.cpp:26-33), then Feature::getPixel with the K(2) / K(5) indexing quirk (Feature.h:60-66)
+        const float fx = (float)((double)last_K_[0] / scale_), fy = (float)((double)last_K_[4] / scale_);
+        const float cx = (float)((double)last_K_[2] / scale_), cy = (float)((double)last_K_[5] / scale_);
+        const std::vector<Vector3f> mus = tc_ekf.featureMus();
+        const std::vector<uint8_t> flags = tc_ekf.deleteFlags();
+        auto put = [&](int x, int y) {
+            if (x < 0 || y < 0 || x >= w || y >= h) return;
+            uint8_t* p = &o.bgr[3 * ((size_t)y * w + x)];
+            p[0] = 0, p[1] = 255, p[2] = 0;  // cv::Scalar(0, 255, 0) in BGR
+        };
+        for (size_t i = 0; i < mus.size(); i++) {
+            if (flags[i]) continue;  // if(!e.flaggedForDeletion()) (:386)
+            const int px = (int)std::nearbyint(mus[i][0] * fx), py = (int)std::nearbyint(mus[i][1] * fy);  // cv::Point(Point2f): cvRound
+            const int r = 22 / 2;  // drawMarker MARKER_SQUARE: the square (x +- size/2, y +- size/2), thickness 1
+            for (int d = -r; d <= r; d++) {
+                put(px + d, py - r), put(px + d, py + r);
+                put(px - r, py + d), put(px + r, py + d);
+            }
+        }
+        // cinfo.K.at(i) = f.K(i), linear index into a column-major Matrix3f (:408-416): the transpose of K
+        const double Kcm[9] = {fx, 0, 0, 0, fy, 0, cx, cy, 1.0};
+        for (int i = 0; i < 9; i++) o.K[i] = Kcm[i];
+        o.P[0] = Kcm[0], o.P[2] = Kcm[2], o.P[5] = Kcm[4], o.P[6] = Kcm[5], o.P[10] = 1.0;  // (:419-423)
+        return o;
     }
+    // EKFVIO::imu_callback (EKFVIO.cpp:113-115).  With cfg.use_imu = 0 (the reference's behaviour) nothing happens.  With
+    // cfg.use_imu = 1 the record is queued and applied, in stamp order, in front of the next frame whose stamp is not
+    // older: ROS delivers 200 Hz IMU messages stamped AFTER an image before that image arrives, and a filter that had
+    // already moved to the IMU stamp would have to refuse the image (dt < 0).  A record older than the filter's time
+    // (it arrived after the frame that should have followed it) is dropped and counted, never an error.
+    void imu_callback(double stamp, const Vector3f& gyro, const Vector3f& accel) {
+        if (!use_imu_) {
+            tc_ekf.chk(ekfvio_imu(tc_ekf.handle(), stamp, gyro.data(), accel.data()));  // the no-op, kept at the boundary
+            return;
+        }
+        if (have_time_ && stamp < t_filter_) {
+            dropped_imu_++;
+            return;
+        }
+        ImuRecord r{stamp, gyro, accel};
+        auto it = imu_queue_.end();
+        while (it != imu_queue_.begin() && (it - 1)->stamp > stamp) --it;  // stable: equal stamps keep arrival order
+        imu_queue_.insert(it, r);
+        if (imu_queue_.size() > 1000) {  // the reference's subscriber queue length (EKFVIO.cpp:80)
+            imu_queue_.pop_front();
+            dropped_imu_++;
+        }
+    }
+    // applies the queued IMU records with stamp <= until (addFrame does this itself)
+    void drainImu(double until) {
+        while (!imu_queue_.empty() && imu_queue_.front().stamp <= until) {
+            const ImuRecord r = imu_queue_.front();
+            imu_queue_.pop_front();
+            if (have_time_ && r.stamp < t_filter_) {
+                dropped_imu_++;
+                continue;
+            }
+            tc_ekf.chk(ekfvio_imu(tc_ekf.handle(), r.stamp, r.gyro.data(), r.accel.data()));
+            t_filter_ = r.stamp;
+            have_time_ = true;
+        }
+    }
+    int droppedImuRecords() const { return dropped_imu_; }
+    size_t queuedImuRecords() const { return imu_queue_.size(); }
 
    private:
+    struct ImuRecord {
+        double stamp;
+        Vector3f gyro, accel;
+    };
     double last_stamp_ = 0;
+    double t_filter_ = 0;  // the stamp the device state stands at (last frame or IMU record applied)
+    bool have_time_ = false;
+    bool use_imu_ = false;
+    int scale_ = 1;
+    std::array<float, 9> last_K_{};
+    std::deque<ImuRecord> imu_queue_;
+    int dropped_imu_ = 0;
 };
 
 }  // namespace ekfvio

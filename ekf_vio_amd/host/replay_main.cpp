@@ -6,7 +6,7 @@
 // final odometry next to the ground truth, the checkSigma numbers and the step rate.
 // Usage: ekfvio_replay [landmarks=256] [frames=300] [seed=0] [dt=0.0333333]
 //        ekfvio_replay --print-config [params.yaml]   (no GPU work: the node's parameter file -> ekfvio_config as JSON)
-//        ekfvio_replay --records <dir> [--out <dir>] [--params params.yaml] [--device n]
+//        ekfvio_replay --records <dir> [--out <dir>] [--params params.yaml] [--device n] [--insight]
 //
 // --records replays what the node's two subscriptions deliver (EKFVIO.cpp:69-81) and writes what its two publishers
 // send (EKFVIO.cpp:444-518), with no ROS in between.  <dir>/records.txt holds one record per line, in arrival order:
@@ -16,7 +16,9 @@
 // cfg.replenish = 1); after it one odometry record and one point-cloud record are appended to
 //     <out>/odom.txt     stamp px py pz qw qx qy qz vx vy vz wx wy wz numeric_ok
 //     <out>/points.txt   "cloud <stamp> <n>" followed by n lines "x y z intensity"
-// (floats printed with %.9g: exact).  IMU records go to imu_callback, a logging stub in the reference.
+// (floats printed with %.9g: exact).  IMU records go to imu_callback, a logging stub in the reference (with imu_update: 1 in
+// the parameter file they are queued and applied in stamp order in front of the next frame).  --insight also writes what
+// publishInsight sends, <out>/insight_NNN.ppm.
 #include <cctype>
 #include <chrono>
 #include <cmath>
@@ -116,33 +118,15 @@ static bool read_pgm(const std::string& path, std::vector<uint8_t>& px, int& w, 
     return (size_t)in.gcount() == px.size();
 }
 
-static int replay_records(const std::string& dir, const std::string& out_dir, const char* params_path, int device) {
+static int replay_records(const std::string& dir, const std::string& out_dir, const char* params_path, int device, bool insight) {
     try {
         ekfvio::Params p = params_path ? ekfvio::Params::fromFile(params_path) : ekfvio::Params();
         if (!params_path) p.cfg.inverse_image_scale = 1;  // no parameter file: frames are used as recorded
         p.cfg.replenish = 1;                              // addFrame runs replenishFeatures itself (EKFVIO.cpp:154, :172)
         std::ifstream rec(dir + "/records.txt");
         if (!rec) throw ekfvio::Error(EKFVIO_EINVAL, "cannot open " + dir + "/records.txt");
-        // the pyramid buffers are sized by the first image
+        // no image size anywhere: the device planes grow with the first frame that needs it (Frame::Frame takes any image)
         std::vector<uint8_t> px;
-        int w = 0, h = 0;
-        {
-            std::ifstream scan(dir + "/records.txt");
-            std::string line;
-            while (std::getline(scan, line)) {
-                std::istringstream ls(line);
-                std::string kind, file;
-                double stamp;
-                if ((ls >> kind >> stamp >> file) && kind == "image") {
-                    if (!read_pgm(dir + "/" + file, px, w, h)) throw ekfvio::Error(EKFVIO_EINVAL, "cannot read " + file);
-                    break;
-                }
-            }
-        }
-        if (w > 0) {
-            p.cfg.max_image_width = w;
-            p.cfg.max_image_height = h;
-        }
         ekfvio::EKFVIO node(p, device);
         FILE* fo = std::fopen((out_dir + "/odom.txt").c_str(), "w");
         FILE* fp = std::fopen((out_dir + "/points.txt").c_str(), "w");
@@ -186,6 +170,18 @@ static int replay_records(const std::string& dir, const std::string& out_dir, co
                 std::fprintf(fp, "cloud %.9f %zu\n", pc.stamp, pc.points.size());
                 for (size_t i = 0; i < pc.points.size(); i++)
                     std::fprintf(fp, "%.9g %.9g %.9g %.9g\n", pc.points[i][0], pc.points[i][1], pc.points[i][2], pc.intensity[i]);
+                if (insight) {  // publishInsight (EKFVIO.cpp:379-442) as a binary PPM (RGB order on disk)
+                    const ekfvio::Insight in = node.insight();
+                    char name[64];
+                    std::snprintf(name, sizeof name, "/insight_%03d.ppm", images);
+                    FILE* fi = std::fopen((out_dir + name).c_str(), "wb");
+                    if (!fi) throw ekfvio::Error(EKFVIO_EINVAL, "cannot write into " + out_dir);
+                    std::fprintf(fi, "P6\n%d %d\n255\n", in.width, in.height);
+                    std::vector<uint8_t> rgb(in.bgr.size());
+                    for (size_t i = 0; i + 2 < rgb.size(); i += 3) rgb[i] = in.bgr[i + 2], rgb[i + 1] = in.bgr[i + 1], rgb[i + 2] = in.bgr[i];
+                    std::fwrite(rgb.data(), 1, rgb.size(), fi);
+                    std::fclose(fi);
+                }
                 images++;
             } else {
                 throw ekfvio::Error(EKFVIO_EINVAL, "records.txt line " + std::to_string(lineno) + ": unknown record kind " + kind);
@@ -196,6 +192,9 @@ static int replay_records(const std::string& dir, const std::string& out_dir, co
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("records: %d images, %d imu; %d landmarks; %.1f frames/s (file reading included)\n", images, imus,
                     node.tc_ekf.numFeatures(), images / el);
+        if (p.cfg.use_imu)
+            std::printf("imu: %d records dropped (older than the filter's time), %zu still queued behind the last frame\n",
+                        node.droppedImuRecords(), node.queuedImuRecords());
         return 0;
     } catch (const ekfvio::Error& e) {
         std::fprintf(stderr, "ekfvio error %d: %s\n", e.code, e.what());
@@ -209,7 +208,17 @@ int main(int argc, char** argv) {
         std::string dir = argv[2], out = argv[2];
         const char* params = nullptr;
         int device = 0;
-        for (int i = 3; i + 1 < argc; i += 2) {
+        bool insight = false;
+        for (int i = 3; i < argc; i += 2) {
+            if (std::strcmp(argv[i], "--insight") == 0) {
+                insight = true;
+                i--;
+                continue;
+            }
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "option %s needs a value\n", argv[i]);
+                return 2;
+            }
             if (std::strcmp(argv[i], "--out") == 0) out = argv[i + 1];
             else if (std::strcmp(argv[i], "--params") == 0) params = argv[i + 1];
             else if (std::strcmp(argv[i], "--device") == 0) device = std::atoi(argv[i + 1]);
@@ -218,7 +227,7 @@ int main(int argc, char** argv) {
                 return 2;
             }
         }
-        return replay_records(dir, out, params, device);
+        return replay_records(dir, out, params, device, insight);
     }
     const int N = argc > 1 ? std::atoi(argv[1]) : 256;
     const int frames = argc > 2 ? std::atoi(argv[2]) : 300;

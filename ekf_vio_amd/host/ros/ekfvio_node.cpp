@@ -90,7 +90,7 @@ class EkfvioNode {
             insight_pub_ = nh_.advertise<sensor_msgs::Image>(p.at("insight_topic"), 1);
             insight_cinfo_pub_ = nh_.advertise<sensor_msgs::CameraInfo>(p.at("insight_camera_info_topic"), 1);
         }
-        if (p.at("use_imu") == "true" || p.at("use_imu") == "1")
+        if (p.at("use_imu") == "true" || p.at("use_imu") == "1")  // "if(USE_IMU)" (EKFVIO.cpp:79-81; default true, Params.h)
             imu_sub_ = nh_.subscribe(p.at("imu_topic"), 1000, &EkfvioNode::imuCallback, this);
         odom_pub_ = nh_.advertise<nav_msgs::Odometry>(p.at("odom_topic"), 1);
         points_pub_ = nh_.advertise<sensor_msgs::PointCloud>(p.at("point_topic"), 1);
@@ -119,7 +119,13 @@ class EkfvioNode {
         const ekfvio::Vector3f gyro{(float)msg->angular_velocity.x, (float)msg->angular_velocity.y, (float)msg->angular_velocity.z};
         const ekfvio::Vector3f acc{(float)msg->linear_acceleration.x, (float)msg->linear_acceleration.y,
                                    (float)msg->linear_acceleration.z};
-        vio_->imu_callback(msg->header.stamp.toSec(), gyro, acc);  // EKFVIO.cpp:113-115 (a logging stub there)
+        // EKFVIO.cpp:113-115 (a logging stub there).  With imu_update the record is queued and applied in stamp order in
+        // front of the next frame (ekfvio::EKFVIO::imu_callback); nothing it can throw may unwind through ros::spin
+        try {
+            vio_->imu_callback(msg->header.stamp.toSec(), gyro, acc);
+        } catch (const ekfvio::Error& e) {
+            ROS_ERROR_STREAM_THROTTLE(1.0, "ekfvio (imu): " << e.what());
+        }
     }
 
     void cameraCallback(const sensor_msgs::ImageConstPtr& img, const sensor_msgs::CameraInfoConstPtr& cam) {
@@ -141,7 +147,7 @@ class EkfvioNode {
             ROS_ERROR_STREAM("ekfvio: " << e.what());
             return;
         }
-        if (publish_insight_) publishInsight(*img, *cam);
+        if (publish_insight_) publishInsight(img->header.stamp);
         publishOdometry(img->header.stamp);
         publishPoints(img->header.stamp);
         const double ms = (ros::WallTime::now() - start).toSec() * 1e3;
@@ -195,34 +201,27 @@ class EkfvioNode {
         points_pub_.publish(msg);
     }
 
-    // EKFVIO.cpp:379-442 draws markers and error ellipses with OpenCV; here: the incoming image with a 5 x 5 cross at
-    // every landmark's pixel (bright for tracked landmarks, dark for flagged ones), no OpenCV needed
-    void publishInsight(const sensor_msgs::Image& in, const sensor_msgs::CameraInfo& cam) {
+    // EKFVIO.cpp:379-442: the resized frame as BGR8 with a green square marker at every landmark that is not flagged for
+    // deletion, and a CameraInfo with the reference's K / P entries; frame id ODOM_FRAME on both (ekfvio::EKFVIO::insight)
+    void publishInsight(const ros::Time& stamp) {
+        const ekfvio::Insight in = vio_->insight();
+        sensor_msgs::CameraInfo cinfo;
+        cinfo.header.frame_id = params_.node.at("odom_frame");
+        cinfo.header.stamp = stamp;
+        cinfo.height = in.height;
+        cinfo.width = in.width;
+        for (int i = 0; i < 9; i++) cinfo.K[i] = in.K[i];
+        for (int i = 0; i < 12; i++) cinfo.P[i] = in.P[i];
+        insight_cinfo_pub_.publish(cinfo);
         sensor_msgs::Image out;
-        out.header = in.header;
+        out.header.frame_id = params_.node.at("odom_frame");
+        out.header.stamp = stamp;
         out.width = in.width;
         out.height = in.height;
-        out.encoding = sensor_msgs::image_encodings::MONO8;
-        out.step = in.width;
-        const uint8_t* src;
-        int step;
-        std::vector<uint8_t> tmp;
-        if (!to_grey(in, tmp, src, step)) return;
-        out.data.resize((size_t)in.width * in.height);
-        for (uint32_t y = 0; y < in.height; y++) std::copy(src + (size_t)y * step, src + (size_t)y * step + in.width, out.data.begin() + (size_t)y * in.width);
-        const std::vector<ekfvio::Vector3f> mus = vio_->tc_ekf.featureMus();
-        const std::vector<uint8_t> flags = vio_->tc_ekf.deleteFlags();
-        for (size_t i = 0; i < mus.size(); i++) {
-            // Feature::getPixel with the reference's K indexing (principal point ignored, Feature.h:60-66), full-resolution frame
-            const int px = (int)std::lrint(cam.K[0] * mus[i][0]), py = (int)std::lrint(cam.K[4] * mus[i][1]);
-            const uint8_t v = flags[i] ? 0 : 255;
-            for (int d = -2; d <= 2; d++) {
-                if (px + d >= 0 && px + d < (int)in.width && py >= 0 && py < (int)in.height) out.data[(size_t)py * in.width + px + d] = v;
-                if (py + d >= 0 && py + d < (int)in.height && px >= 0 && px < (int)in.width) out.data[(size_t)(py + d) * in.width + px] = v;
-            }
-        }
+        out.encoding = sensor_msgs::image_encodings::BGR8;
+        out.step = 3 * in.width;
+        out.data = in.bgr;
         insight_pub_.publish(out);
-        insight_cinfo_pub_.publish(cam);
     }
 
     ros::NodeHandle nh_;

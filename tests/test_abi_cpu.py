@@ -149,3 +149,11 @@ def test_ros_node_source_type_checks_against_stub_headers():
     for needle in ("subscribeCamera", "advertise<nav_msgs::Odometry>", "advertise<sensor_msgs::PointCloud>", "waitForTransform",
                    "\"intensity\"", "imu_topic", "sendTransform"):
         assert needle in text, needle
+
+
+def test_committed_pivot_chain_is_what_its_generator_emits():
+    """ekf_vio_amd/csrc/potrf_chain.inc is generated (scripts/gen_potrf_chain.py) and compiled into the product: the
+    committed file must be exactly what the generator emits today, so an edit of either without the other fails here."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "gen_potrf_chain.py")]).decode()
+    have = open(os.path.join(ROOT, "ekf_vio_amd", "csrc", "potrf_chain.inc")).read()
+    assert out == have

@@ -154,9 +154,14 @@ def test_gaussian_blur_before_fast_bit_exact(sigma, scale, crop):
     v.tc_ekf.close()
 
 
-def test_negative_blur_sigma_is_rejected():
-    v = EKFVIO(max_features=8, fast_blur_sigma=-1.0)
+def test_replenishment_parameters_are_validated_at_create():
+    """A frame must not fail half-way through for a parameter known at start-up: a negative blur sigma or an
+    occupancy radius beyond what the selection kernel's circle rows cover is refused by ekfvio_create."""
+    for bad in (dict(fast_blur_sigma=-1.0), dict(min_new_feature_dist=64), dict(min_new_feature_dist=-1)):
+        with pytest.raises(capi.EkfvioError) as e:
+            EKFVIO(max_features=8, **bad)
+        assert e.value.code == capi.EINVAL
+    v = EKFVIO(max_features=8, min_new_feature_dist=63, fast_blur_sigma=0.0)
     v.addFrame(1.0, grey("640_480_test"), K)
-    with pytest.raises(capi.EkfvioError):
-        v.replenishFeatures()
+    assert len(v.replenishFeatures()) >= 1
     v.tc_ekf.close()

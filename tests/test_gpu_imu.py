@@ -80,14 +80,14 @@ def test_imu_callback_is_a_no_op_by_default_and_a_predict_plus_update_behind_the
             e.process(sc.dt)
             e.updateWithFeaturePositions(z, R, p)
         before = e.get_state()
-        v.imu_callback(1.000, [0.0, 0.1, 0.0], [0.0, -9.81, 0.0])   # first record: only sets the filter's time
+        v.imu_now(1.000, [0.0, 0.1, 0.0], [0.0, -9.81, 0.0])   # first record: only sets the filter's time
         mid = e.get_state()
-        v.imu_callback(1.005, [0.0, 0.1, 0.0], [0.0, -9.81, 0.0])   # 5 ms later: process(0.005) + update when enabled
+        v.imu_now(1.005, [0.0, 0.1, 0.0], [0.0, -9.81, 0.0])   # 5 ms later: process(0.005) + update when enabled
         after = e.get_state()
         states[flag] = (before, mid, after)
         if flag:
             with pytest.raises(capi.EkfvioError) as ex:
-                v.imu_callback(0.9, [0, 0, 0], [0, 0, 0])           # a stamp before the filter's time
+                v.imu_now(0.9, [0, 0, 0], [0, 0, 0])           # a stamp before the filter's time
             assert ex.value.code == capi.EINVAL
         e.close()
     b0, m0, a0 = states[0]
@@ -119,13 +119,13 @@ def test_imu_records_between_frames_keep_the_closed_loop_on_track():
         e = v.tc_ekf
         e.addNewFeatures(truth.initial_features())
         t = 0.0
-        v.imu_callback(t, truth.omega, truth.acc - rot_t(truth.quat, np.array(G)))  # sets the filter's clock
+        v.imu_now(t, truth.omega, truth.acc - rot_t(truth.quat, np.array(G)))  # sets the filter's clock
         for _ in range(frames):
             for k in range(8):
                 truth.advance()
                 t += tick
                 if flag:
-                    v.imu_callback(t, truth.omega, truth.acc - rot_t(truth.quat, np.array(G)))
+                    v.imu_now(t, truth.omega, truth.acc - rot_t(truth.quat, np.array(G)))
             if not flag:
                 e.process(np.float32(8 * tick))
             z, R, p = truth.measure()
