@@ -64,7 +64,7 @@ def test_add_features_on_dense_sigma_host_count():
         g.process(sc.dt)
         assert g.updateWithFeaturePositions(z[:N0], R[:N0], p[:N0]) in (capi.OK, capi.ENUMERIC)
     st = g.get_state()
-    assert np.count_nonzero(st["Sigma"]) > 0.9 * st["Sigma"].size
+    assert np.count_nonzero(st["Sigma"]) > 0.8 * st["Sigma"].size
     o32.set_state(st)
     g.addNewFeatures(uv_all[N0:]), o32.add_new_features(uv_all[N0:])
     sg, so = g.get_state(), o32.get_state()
@@ -98,8 +98,8 @@ def test_add_features_on_dense_sigma_device_count():
     sequence loses landmarks to the kill box, so frames 2.. replenish onto a dense covariance."""
     base = grey()
     seq = translated_sequence(base, 5, dx=-6.0, dy=-2.5)  # fast enough that landmarks leave through the kill box
-    v = EKFVIO(max_features=48, replenish=1)
-    node = OracleNode(48, K)
+    v = EKFVIO(max_features=160, replenish=1)  # more than one 640x480 frame yields at 30 px spacing: every frame may add
+    node = OracleNode(160, K)
     grew = 0
     for i, img in enumerate(seq):
         stamp = 2.0 + i / 30.0
@@ -134,10 +134,10 @@ def test_teacher_forced_image_loop_with_replenishment():
     state: pass flags, landmark count, new landmarks' pixels and last_klt bit-exact; the state within the yardstick."""
     base = grey()
     seq = translated_sequence(base, 10, dx=-3.1, dy=-1.3)
-    v = EKFVIO(max_features=64, replenish=1)
-    node = OracleNode(64, K)
+    v = EKFVIO(max_features=160, replenish=1)  # never full: the replenishment adds landmarks on later frames too
+    node = OracleNode(160, K)
     o64 = OracleFilter(np.float64)
-    updates = 0
+    updates = grown = 0
     for i, img in enumerate(seq):
         stamp = 7.0 + i / 30.0
         if i > 0:
@@ -156,6 +156,7 @@ def test_teacher_forced_image_loop_with_replenishment():
                 assert np.array_equal(sg[k], so[k]), k
             continue
         updates += 1
+        grown += len(node.last["new_px"]) > 0
         pre = node.last["pre_update"]
         o64.set_state(pre)
         o64.update(node.last["z"], node.last["R"], node.last["passed"])
@@ -172,7 +173,7 @@ def test_teacher_forced_image_loop_with_replenishment():
         assert r_g <= yard["sig"] + ACC_FACTOR * r_o + SIG_FLOOR, (i, r_g, r_o, yard)
         if rc_o == 0:
             assert rc_g == capi.OK, i
-    assert updates == 9
+    assert updates == 9 and grown >= 2
     v.tc_ekf.close()
 
 
@@ -208,7 +209,7 @@ def test_free_running_loop_loses_what_the_oracle_loop_loses():
     n1 = min(n_g, n_o)
     both = (sg["del_flag"][:n1] == 0) & (so["del_flag"][:n1] == 0)
     same_start = both.copy()
-    assert both.sum() > 100
+    assert both.sum() > 0.7 * n1
     d = (sg["last_klt"][:n1][same_start] - so["last_klt"][:n1][same_start]) * np.array([K[0], K[4]], np.float32)
     assert np.median(np.abs(d)) < 0.05  # pixels
     v.tc_ekf.close()
