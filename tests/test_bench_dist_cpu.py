@@ -53,3 +53,18 @@ def test_gpus_flag_that_disagrees_with_the_launcher_fails_loudly():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-dist"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_run_with_its_stderr():
+    """rank 1 dying at import / rendezvous used to leave rank 0 in the process group's barrier for its
+    timeout with no diagnostic.  The self-spawning parent now polls every child, ends the others and shows the failed
+    rank's stderr."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["EKFVIO_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-dist"], env=env,
+                         capture_output=True, text=True, timeout=150)
+    assert out.returncode != 0 and time.time() - t0 < 120
+    assert "rank 1 exited" in out.stderr and "dies before the rendezvous" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
