@@ -21,6 +21,8 @@
 // K-padding of both operands is zero.
 #include "common.h"
 
+#include <algorithm>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -359,7 +361,7 @@ template <int BMt, int WPS, int EPI>
 __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float beta, const float* Cin,
                                                      int ldcin, float* C, int ldc, int flush, int lowerB, GemmEpi epi,
-                                                     int tiles_x) {
+                                                     int tiles_x, int tiles_y, int strip_w) {
     constexpr int RB = BMt / 16;                            // 16-row blocks per wavefront
     constexpr int SA = (BMt % 32 == 16) ? BMt : BMt + 16;   // LDS row strides, both = 16 mod 32
     constexpr int SB = 80;
@@ -377,8 +379,29 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     const int nwg = gridDim.x;
     const int bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
     const int swz = xcd * bq + min(xcd, br) + (blockIdx.x >> 3);
-    const int i0 = (swz % tiles_x) * BMt;
-    const int j0 = (swz / tiles_x) * 64;
+    // strip_w == 0 (production): the run goes down whole tile columns.  strip_w > 0 (EKFVIO_GEMM_STRIP, measured and not
+    // adopted): a compact 2-D patch instead -- strips of strip_w tile columns walked row by row, odd strips bottom-up.  At
+    // 790 x 790 x 512 that cuts the fabric-side traffic of a Joseph GEMM from 22.3 to 16.8 MB per launch (each XCD's L2
+    // fetches ~7 row panels of A and ~5 column panels of B instead of all 17 and 2-3) and the pair replayed back to back
+    // from 12.3 to 11.9 us, but inside the filter step the first Joseph GEMM gets SLOWER (12.76 -> 13.17 us by rocprofv3,
+    // step 120.3 -> 121.0 us, same box, three interleaved repetitions: profiles/r03_gemm_tile_order_experiment.txt): the
+    // operands were written by the previous kernel, every L2 is cold for them either way, and the whole-column runs are
+    // what leaves every L2 holding all of K for the second GEMM.
+    int ti, tj;
+    if (strip_w <= 0) {
+        ti = swz % tiles_x;
+        tj = swz / tiles_x;
+    } else {
+        const int per = tiles_x * strip_w;
+        const int sidx = swz / per;
+        const int rem = swz - sidx * per;
+        const int w = min(strip_w, tiles_y - sidx * strip_w);
+        const int rr = rem / w;
+        ti = (sidx & 1) ? tiles_x - 1 - rr : rr;
+        tj = sidx * strip_w + (rem - rr * w);
+    }
+    const int i0 = ti * BMt;
+    const int j0 = tj * 64;
 
 #ifdef EKF_GEMM_STAMPS
     long long* stamps_ = (blockIdx.x == 9 && threadIdx.x == 0) ? epi.stamps : nullptr;
@@ -696,6 +719,42 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     GSTAMP(38);
 }
 
+// EKFVIO_GEMM_STRIP=<w> (diagnostic): gemm16_kernel's tile order in strips of w tile columns; -1 picks the width that
+// minimises the operand panels the eight XCD L2s fetch between them, counted as the kernel assigns tiles.  Unset / 0:
+// the production order (see the kernel).
+static int xcd_strip_width(int tx, int ty, int bm) {
+    static const int forced = getenv("EKFVIO_GEMM_STRIP") ? atoi(getenv("EKFVIO_GEMM_STRIP")) : 0;
+    if (forced == 0) return 0;
+    if (forced > 0) return forced < ty ? forced : ty;
+    const int nwg = tx * ty, bq = nwg >> 3, br = nwg & 7;
+    long best = -1;
+    int best_w = ty;
+    std::vector<unsigned char> rows(tx), cols(ty);
+    for (int w = 1; w <= ty; w++) {
+        long cost = 0;
+        int pos = 0;
+        for (int x = 0; x < 8; x++) {
+            const int cnt = bq + (x < br ? 1 : 0);
+            std::fill(rows.begin(), rows.end(), 0);
+            std::fill(cols.begin(), cols.end(), 0);
+            for (int q = pos; q < pos + cnt; q++) {
+                const int per = tx * w, sidx = q / per, rem = q - sidx * per;
+                const int ww = std::min(w, ty - sidx * w), rr = rem / ww;
+                rows[(sidx & 1) ? tx - 1 - rr : rr] = 1;
+                cols[sidx * w + (rem - rr * ww)] = 1;
+            }
+            pos += cnt;
+            for (int r = 0; r < tx; r++) cost += rows[r] ? bm : 0;
+            for (int c = 0; c < ty; c++) cost += cols[c] ? 64 : 0;
+        }
+        if (best < 0 || cost < best) {
+            best = cost;
+            best_w = w;
+        }
+    }
+    return best_w;
+}
+
 // cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
 // (512 threads); +100 = the same with 256 threads
 static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -725,9 +784,10 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         const int bm = cfg % 100;
         const int tx = (M + bm - 1) / bm;
         dim3 grid(tx * ty);
+        const int sw = xcd_strip_width(tx, ty, bm);
 #define GEMM16_GO(BMv, W, EP)                                                                                           \
     hipLaunchKernelGGL((gemm16_kernel<BMv, W, EP>), grid, dim3(256 * W), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, \
-                       ldc, flush, lowerB, e, tx)
+                       ldc, flush, lowerB, e, tx, ty, sw)
 #define GEMM16_BM(W, EP)                          \
     do {                                          \
         if (bm == 32) GEMM16_GO(32, W, EP);       \

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python3 $ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline > $OUT/pmc_${TAG}_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python3 $ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-full-loop > $OUT/pmc_${TAG}_$c.log 2>&1
   rc=$?
   echo "pmc $c rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 $OUT/pmc_${TAG}_$c.log; exit $rc; fi
