@@ -225,6 +225,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_SCHUR");  // tuning knob: 1 = Sigma (I - K H)^T and K as Schur tiles inside the sweep instead of two GEMMs behind it
         if (e) f->schur = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_FRAME_OUTPUTS");  // tuning knob: 0 = the frame's last kernel publishes the status word only
+        if (e) f->frame_outputs = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches
         if (e) f->fuse_linearize = atoi(e) ? 1 : 0;
     }
@@ -303,6 +305,7 @@ const char* ekfvio_last_error(const ekfvio_filter* f) {
 
 int ekfvio_reset(ekfvio_filter* f) {
     if (!f) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     HIPC(f, hipSetDevice(f->device));
     f->N = 0;
     f->n = EKF_BASE;
@@ -321,6 +324,7 @@ int ekfvio_reset(ekfvio_filter* f) {
 
 int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count) {
     if (!f || count < 0 || (count > 0 && !uv)) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     if (count == 0) return EKFVIO_OK;  // reference: early return (:59)
     if (f->N + count > f->cfg.max_features) return EKFVIO_ECAPACITY;
     HIPC(f, hipSetDevice(f->device));
@@ -331,6 +335,7 @@ int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count) {
 
 int ekfvio_process(ekfvio_filter* f, float dt) {
     if (!f || !(dt >= 0.f)) return EKFVIO_EINVAL;  // ROS_ASSERT(dt >= 0) EKFVIO.cpp:162
+    f->out_fresh = false;
     HIPC(f, hipSetDevice(f->device));
     launch_predict(f, dt);
     HIPC(f, hipGetLastError());
@@ -358,6 +363,7 @@ static int finish_update(ekfvio_filter* f) {
 
 int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count) {
     if (!f || count != f->N) return EKFVIO_EINVAL;  // ROS_ASSERT :478
+    f->out_fresh = false;
     if (count > 0 && (!z || !R || !pass)) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
     const int m = count_rows(pass, count);
@@ -395,6 +401,10 @@ int ekfvio_dim(const ekfvio_filter* f) { return f ? f->n : -1; }
 
 int ekfvio_get_base_mu(ekfvio_filter* f, float* base_mu) {
     if (!f || !base_mu) return EKFVIO_EINVAL;
+    if (f->out_fresh) {  // written with the frame's status word (ekfvio_step_image): nothing to launch, nothing to wait for
+        memcpy(base_mu, f->h_out, sizeof(float) * EKF_BASE);
+        return EKFVIO_OK;
+    }
     HIPC(f, hipSetDevice(f->device));
     // 22 floats: written by a kernel straight into pinned host memory and awaited like the status word (the node reads
     // its odometry every frame: a device-to-host copy into pageable memory plus a synchronise cost three times as much)
@@ -502,6 +512,7 @@ int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym) {
 int ekfvio_set_state(ekfvio_filter* f, int32_t N, const float* base_mu, const float* mu3N, const float* last_klt2N,
                      const uint8_t* delN, const float* sigma, int32_t ld) {
     if (!f || N < 0 || !base_mu || !sigma) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     if (N > f->cfg.max_features) return EKFVIO_ECAPACITY;
     const int n = EKF_BASE + 3 * N;
     if (ld < n || (N > 0 && (!mu3N || !last_klt2N || !delN))) return EKFVIO_EINVAL;
@@ -525,6 +536,7 @@ int ekfvio_set_state(ekfvio_filter* f, int32_t N, const float* base_mu, const fl
 
 int ekfvio_imu_update(ekfvio_filter* f, const float* gyro, const float* accel) {
     if (!f || !gyro || !accel) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     HIPC(f, hipSetDevice(f->device));
     launch_imu_update(f, gyro, accel);
     HIPC(f, hipGetLastError());
@@ -533,6 +545,7 @@ int ekfvio_imu_update(ekfvio_filter* f, const float* gyro, const float* accel) {
 
 int ekfvio_imu(ekfvio_filter* f, double stamp, const float* gyro, const float* accel) {
     if (!f) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     if (!f->cfg.use_imu) return EKFVIO_OK;  // the reference's callback only logs
     if (!gyro || !accel) return EKFVIO_EINVAL;
     if (!f->have_stamp) {  // tc_ekf.t is set by the first message (EKFVIO.cpp:148-150 does it for the first frame)
@@ -622,6 +635,7 @@ static int capture_steps(ekfvio_filter* f, int steps, int m, float dt, int* coun
 
 int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt) {
     if (!f || f->seq_frames <= 0 || f->seq_N != f->N || count < 0 || first < 0 || !(dt >= 0.f)) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     HIPC(f, hipSetDevice(f->device));
     const size_t N = f->N;
     int s = 0;

@@ -120,6 +120,10 @@ struct ekfvio_filter {
     // waits with wait_status: no device-to-host copy into pageable memory, no interrupt-driven synchronise
     float* h_out = nullptr;    // pinned, device-mapped: EKF_BASE + 4 * max_features floats
     float* d_out = nullptr;    // the device's address of h_out
+    int frame_outputs = 1;     // 1: ekfvio_step_image's last kernel also writes the node's outputs (EKFVIO_FRAME_OUTPUTS=0: status word only)
+    bool out_fresh = false;    // h_out holds base_mu and the point cloud of the CURRENT state and frame: ekfvio_step_image's last
+                               // kernel writes them with the status word, and every call that changes the state or the frame
+                               // clears the flag; while it is set the node's getters cost a memcpy
     unsigned char* h_meas = nullptr;  // pinned staging for one frame's (z, R, pass): one H2D copy per ekfvio_update
     unsigned char* d_meas = nullptr;  // its device image: z at 0, R at 8N_cap, pass at 24N_cap bytes
     // uploaded measurement sequences

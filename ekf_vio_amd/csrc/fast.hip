@@ -534,6 +534,7 @@ int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out) {
 // EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame
 int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy) {
     if (!f) return EKFVIO_EINVAL;
+    f->out_fresh = false;
     if (added) *added = 0;
     int enq = 0;
     int rc = replenish_enqueue(f, &enq);

@@ -150,6 +150,14 @@ def test_teacher_forced_image_loop_with_replenishment():
         assert np.array_equal(sg["del_flag"], so["del_flag"]), i      # pass flags (a failed landmark is flagged, :528)
         assert np.array_equal(sg["last_klt"], so["last_klt"]), i      # tracker results and the new landmarks' positions
         assert np.array_equal(sg["feat_mu"][n_before:], so["feat_mu"][n_before:]), i  # = the new landmarks' pixels
+        # what the node publishes after addFrame arrives with the frame's status word (frame_outputs_kernel): it must be the
+        # state's own numbers, new landmarks included (their count is only known on the device when the kernel runs)
+        od = v.odometry()
+        xyz, inten = v.points()
+        assert np.array_equal(od["position"], sg["base_mu"][0:3]) and np.array_equal(od["orientation_wxyz"], sg["base_mu"][3:7])
+        zinv = (1.0 / sg["feat_mu"][:, 2].astype(np.float64)).astype(np.float32)
+        assert xyz.shape == (v.tc_ekf.num_features, 3)
+        assert np.array_equal(xyz, np.stack([sg["feat_mu"][:, 0] * zinv, sg["feat_mu"][:, 1] * zinv, zinv], axis=1)), i
         if i == 0:
             assert len(node.last["new_px"]) > 10
             for k in KEYS:
