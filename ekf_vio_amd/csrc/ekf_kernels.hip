@@ -457,9 +457,21 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
                                                             const float* __restrict__ FA, const float* __restrict__ FB,
                                                             const float* __restrict__ FD, float dt,
                                                             float* __restrict__ Pout, int tiles_side, int chunks,
-                                                            const float* __restrict__ mu, float* __restrict__ mu_next, BookArgs book) {
+                                                            const float* __restrict__ mu, float* __restrict__ mu_next, BookArgs book,
+                                                            long long* dbg) {
     const int tid = threadIdx.x;
     const int ntile = tiles_side * tiles_side;
+    // diagnostic phase stamps (scripts/predict_stamps.py; dbg is null in production): one diagonal tile, one off-diagonal
+    // tile, base workgroup 0, one base-row and one base-column workgroup
+#define PSTAMP_(slot)                                                                                               \
+    do {                                                                                                            \
+        if (dbg && tid == 0) {                                                                                      \
+            const int b_ = (int)blockIdx.x;                                                                         \
+            const int w_ = b_ == 0 ? 0 : b_ == 1 ? 1 : b_ == ntile ? 2 : b_ == ntile + 1 ? 3 : b_ == ntile + chunks + 1 ? 4 : -1; \
+            if (w_ >= 0) dbg[700 + 8 * w_ + (slot)] = (long long)__builtin_amdgcn_s_memtime();                      \
+        }                                                                                                           \
+    } while (0)
+    PSTAMP_(0);
     __shared__ float sm[4096];
     __shared__ float s_base[EKF_BASE];
     __shared__ BaseMotion s_bm[19];
@@ -548,6 +560,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
             }
         }
         __syncthreads();
+        PSTAMP_(1);
         if (LIN) {
 #ifdef EKF_PREDICT_LIN_TWO_BARRIERS
             if (tid < 19) s_bm[tid] = lin_base_motion(s_base, tid, dt);
@@ -576,6 +589,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
             }
             __syncthreads();
         }
+        PSTAMP_(2);
         // X on the base columns, once per landmark row of the tile
         for (int e = tid; e < PT * 27; e += 256) {
             const int l = e / 27, r = (e % 27) / 9, b = e % 9;
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
             sXb[e] = acc;
         }
         __syncthreads();
+        PSTAMP_(3);
         const int lf = tid / PT, lg = tid % PT;
         const int f = f0 + lf, g = g0 + lg;
         if (f >= N || g >= N) return;
@@ -619,6 +634,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
                 const int i = EKF_BASE + 3 * f + r, j = EKF_BASE + 3 * g + sIdx;
                 Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
             }
+        PSTAMP_(4);
         return;
     }
     const int wb = (int)blockIdx.x - ntile;
@@ -669,6 +685,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         FBp = sLB;
         FDp = sLD;
         __syncthreads();  // A and the landmarks' B, D blocks are in LDS
+        PSTAMP_(1);
     } else {
         for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) sA[e] = FA[e];
     }
@@ -692,6 +709,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
                 for (int k = 0; k < EKF_BASE; k++) acc = acc + sX1[k * EKF_BASE + i] * sA[k * EKF_BASE + j];
                 Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
             }
+            PSTAMP_(4);
             return;
         }
         const int g0 = (wb - 1) * PC, j0 = EKF_BASE + 3 * g0;
@@ -714,6 +732,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
             for (int q = 0; q < 3; q++) acc = acc + sX2[(3 * (jc / 3) + q) * EKF_BASE + i] * d[q * 3];
             Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
         }
+        PSTAMP_(4);
         return;
     }
     // ---- base columns: j < 22; rows of landmark chunk wb-chunks-1 ----
@@ -740,7 +759,9 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
             const int i = i0 + ic;
             Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
         }
+        PSTAMP_(4);
     }
+#undef PSTAMP_
 }
 
 // dense mode epilogue: P += Q(dt) on the diagonal, then prune
@@ -900,10 +921,10 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
         if (book && lin_in_predict) b = *book;
         if (lin_in_predict)
             hipLaunchKernelGGL(predict_fused_kernel<true>, dim3(ts * ts + 1 + 2 * chunks + (b.enabled ? 1 : 0)), dim3(256), 0, f->stream,
-                               f->P, ld, f->N, n, f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b);
+                               f->P, ld, f->N, n, f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b, f->sweep_dbg);
         else
             hipLaunchKernelGGL(predict_fused_kernel<false>, dim3(ts * ts + 1 + 2 * chunks), dim3(256), 0, f->stream, f->P, ld, f->N, n,
-                               f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b);
+                               f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b, f->sweep_dbg);
         std::swap(f->P, f->P2);  // out of place; P2's padding is zero as well (never written outside n x n)
     }
     // the propagated mean becomes the state (landmarks used the OLD base state, :102-107)
