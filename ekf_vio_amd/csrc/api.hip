@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 
 #include "common.h"
@@ -214,13 +215,17 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Lsign, (size_t)(f->m_cap / 64 > 256 ? f->m_cap / 64 : 256)));  // 256: the raw-solve test hook goes up to m = 16384
-    HIPC(f, dev_alloc(f->stream, &f->sweep_sync, 2 * (size_t)(f->m_cap / 64 > 128 ? f->m_cap / 64 : 128) + 4));
+    {   // flags of the persistent sweeps: mode 1: 2 mb + 4 words; mode 2: ready[mb] + fin[row blocks x mb] + 4 (used below 16 block columns)
+        const size_t mbc = (size_t)(f->m_cap / 64 > 128 ? f->m_cap / 64 : 128);
+        const size_t mb2 = (size_t)std::min(f->m_cap / 64, 16);
+        HIPC(f, dev_alloc(f->stream, &f->sweep_sync, std::max(2 * mbc + 4, mb2 + (size_t)(f->ld_aug / 64 + 1) * mb2 + 8)));
+    }
     {
         hipDeviceProp_t prop;
         HIPC(f, hipGetDeviceProperties(&prop, device));
         f->num_cus = prop.multiProcessorCount;
         const char* e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
-        if (e) f->sweep_mode = atoi(e) ? 1 : 0;
+        if (e) f->sweep_mode = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
         e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_SCHUR");  // tuning knob: 1 = Sigma (I - K H)^T and K as Schur tiles inside the sweep instead of two GEMMs behind it

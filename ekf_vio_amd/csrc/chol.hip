@@ -1545,6 +1545,8 @@ __global__ __launch_bounds__(256) void chol_sweep_kernel(float* __restrict__ S, 
     }
 }
 
+#include "chol_persist.inc"
+
 }  // namespace
 
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps) {
@@ -1570,6 +1572,18 @@ void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_o
                        f->Linv, f->info, f->Lsign, f->sweep_dbg);
 }
 
+// helpers of the persistent sweep (chol_persist.inc): per block column j the rows of A from the diagonal down (without
+// (1,1)), the X row blocks and the identity row blocks 0 .. j
+static int persist_helpers(int mb, int nX) {
+    int h = 0;
+    for (int j = 1; j < mb; j++) h += (mb - j - (j == 1 ? 1 : 0)) + nX + (j + 1);
+    return h;
+}
+bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
+    const int mb = m_pad / PB;
+    return f->sweep_mode == 2 && mb >= 2 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus;
+}
+
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done,
                        bool schur) {
     ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad +
@@ -1590,6 +1604,21 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     }
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
+    if (!schur && sweep_is_persistent(f, m_pad, n_pad)) {
+        // ONE launch for everything behind the first diagonal tile (chol_persist.inc): flags zeroed, then the chain and its helpers
+        PersistArgs pa;
+        pa.S = Saug, pa.lds = ld, pa.L = Laug, pa.ldl = ld, pa.Linv = Linv;
+        pa.mb = mb, pa.idb0 = idb0, pa.nrows = mb + rb;
+        pa.info = f->info, pa.Lsign = f->Lsign;
+        pa.ready = f->sweep_sync;
+        pa.fin = f->sweep_sync + mb;
+        pa.abort_flag = f->sweep_sync + mb + (mb + rb) * mb;
+        pa.dbg = f->sweep_dbg;
+        { const char* e = getenv("EKFVIO_PERSIST_DBG"); pa.dbg_mode = e ? atoi(e) : 0; }
+        (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * (size_t)(mb + (mb + rb) * mb + 4), f->stream);
+        hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
+        return;
+    }
     // many tiles per step: panel blocks once per step in a launch of their own instead of twice per tile
     const bool split = mb >= EKF_SWEEP_SPLIT_MB;
     SchurArgs sc;

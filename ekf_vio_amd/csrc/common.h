@@ -99,7 +99,8 @@ struct ekfvio_filter {
     float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
     unsigned long long* Lsign = nullptr;  // [>= m_cap/64] per block column: mask of negative pivots (0 = positive definite block)
     int* sweep_sync = nullptr; // [2*m_cap/64 + 4] ready/done counters + abort flag of the persistent sweep
-    int sweep_mode = 0;        // 0: one launch per block step; 1: one persistent launch (chol_sweep_kernel)
+    int sweep_mode = 0;        // 0: one launch per block step; 1: round 1's persistent launch (chol_sweep_kernel); 2: the persistent
+                               // launch with per-tile hand-offs (chol_persist.inc)
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
     int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.
@@ -271,6 +272,7 @@ int launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps);  // returns 
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld,
                        bool first_tile_done = false, bool schur = false);
 bool sweep_supports_schur(const ekfvio_filter* f, int m_pad);
+bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad);
 // K pruned, G = K R - T[:, idx], K y partial sums (one row of f->Wt per 64 measurement columns)
 void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false, bool with_wt = true);

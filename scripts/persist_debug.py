@@ -1,0 +1,43 @@
+"""Which tiles of the factor / of the solve differ between the per-step sweep and the persistent per-tile sweep."""
+import os, sys, subprocess, json
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    from ekf_vio_amd import TightlyCoupledEKF
+    m, nr = int(sys.argv[2]), int(sys.argv[3])
+    rng = np.random.default_rng(7)
+    Q = rng.standard_normal((m, m))
+    S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
+    Cr = rng.standard_normal((nr, m)).astype(np.float32)
+    g = TightlyCoupledEKF(max_features=4)
+    L, X, info = g.test_cholesky_solve(S, Cr)
+    np.save(sys.argv[4] + "_L.npy", L); np.save(sys.argv[4] + "_X.npy", X)
+    print("info", info)
+    sys.exit(0)
+m, nr = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 150)
+for mode in ("0", "2"):
+    env = dict(os.environ, EKFVIO_SWEEP=mode)
+    out = subprocess.run([sys.executable, __file__, "child", str(m), str(nr), "/tmp/pd_" + mode], env=env, capture_output=True, text=True)
+    print("mode", mode, out.stdout.strip(), out.stderr.strip()[-300:])
+F0, F2 = np.load("/tmp/pd_0_L.npy"), np.load("/tmp/pd_2_L.npy")
+L0, L2 = np.tril(F0), np.tril(F2)
+X0, X2 = np.load("/tmp/pd_0_X.npy"), np.load("/tmp/pd_2_X.npy")
+mb = (m + 63) // 64
+print("L tiles that differ (row, col): max abs diff")
+for i in range(mb):
+    print(" ".join("%9.2e" % np.abs(L0[64 * i:64 * i + 64, 64 * j:64 * j + 64] - L2[64 * i:64 * i + 64, 64 * j:64 * j + 64]).max() if j <= i else "    -    " for j in range(mb)))
+print("X = C S^-1 column blocks: max abs diff", [float(np.abs(X0[:, 64 * j:64 * j + 64] - X2[:, 64 * j:64 * j + 64]).max()) for j in range(mb)])
+print("X row blocks:", [float(np.abs(X0[64 * i:64 * i + 64] - X2[64 * i:64 * i + 64]).max()) for i in range((nr + 63) // 64)])
+
+if int(os.environ.get("EKFVIO_PERSIST_DBG", "0")) & 8:
+    rng = np.random.default_rng(7)
+    Q = rng.standard_normal((m, m))
+    S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
+    for k in range(1, mb - 1):
+        i = k + 1
+        want = S[64 * i:64 * i + 64, 64 * k:64 * k + 64].astype(np.float64)
+        for q in range(k):
+            want -= L0[64 * i:64 * i + 64, 64 * q:64 * q + 64].astype(np.float64) @ L0[64 * k:64 * k + 64, 64 * q:64 * q + 64].T
+        seen = F2[64 * k:64 * k + 64, 64 * i:64 * i + 64]
+        orig = S[64 * i:64 * i + 64, 64 * k:64 * k + 64]
+        print("chain saw tile (%d,%d): vs final %.2e, vs original %.2e" % (i, k, np.abs(seen - want).max(), np.abs(seen - orig).max()))

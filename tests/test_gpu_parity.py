@@ -570,3 +570,71 @@ def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
         assert relf(out[mode]["Sigma"], s64["Sigma"]) <= ACC_FACTOR * relf(s32["Sigma"], s64["Sigma"]) + SIG_FLOOR, mode
     assert np.array_equal(out["1"]["last_klt"], out["0"]["last_klt"]) and np.array_equal(out["1"]["del_flag"], out["0"]["del_flag"])
     assert relf(out["1"]["Sigma"], out["0"]["Sigma"]) < 2e-5 and maxabs(out["1"]["base_mu"], out["0"]["base_mu"]) < 2e-5
+
+
+@pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (100, 3), (64, 0), (40, 5), (33, 0)])
+def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkeypatch, N, fails):
+    """EKFVIO_SWEEP=2 (chol_persist.inc): everything behind the first diagonal tile in ONE launch -- the chain workgroup
+    keeps L_kk in LDS from step to step, every other tile has an owner workgroup that keeps it in registers for the whole
+    sweep, hand-offs are write-through stores behind per-tile flags.  Same per-tile arithmetic in the same order as one
+    launch per block step: every bit of the state must agree, per call and in graph replay, with ragged measurement
+    counts and with one, two, four and eight block columns."""
+    sc = Scenario(N, seed=11)
+    fr = list(sc.frames(5))
+    for s, (z, R, p) in enumerate(fr):
+        for q in range(fails):
+            p[(7 * q + 3 * s + 1) % N] = 0
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("EKFVIO_SWEEP", mode)
+        for replay in (False, True):
+            g = TightlyCoupledEKF(max_features=N)
+            g.addNewFeatures(sc.initial_features())
+            if replay:
+                g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+                g.run_uploaded(0, len(fr), sc.dt)
+                g.synchronize()
+            else:
+                for z, R, p in fr:
+                    g.process(sc.dt)
+                    assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
+            out[(mode, replay)] = g.get_state()
+            g.close()
+    ref = out[("0", False)]
+    assert np.isfinite(ref["Sigma"]).all()
+    for key, st in out.items():
+        for k in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"):
+            assert np.array_equal(st[k], ref[k]), (key, k)
+
+
+@pytest.mark.parametrize("where", [(3,), (40,), (3, 40, 70, 120)])
+def test_persistent_per_tile_sweep_through_the_signed_factorisation(monkeypatch, where):
+    """The rare path inside the persistent sweep: a diagonal tile that meets a non-positive pivot is factored again as
+    U S U^T and its sign mask travels with ready[k] to every helper (round 1's persistent sweep had no signed
+    path).  The covariance gets an indefinite 2x2 (u, v) block for the landmarks in `where` (landmark q's rows are
+    measurement rows 2q, 2q+1: the first launch's tile for q < 32, the sweep's steps beyond).  Both forms of the sweep
+    must flag it and agree bit for bit."""
+    N = 128
+    sc = Scenario(N, seed=2)
+    fr = list(sc.frames(3))
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("EKFVIO_SWEEP", mode)
+        g = TightlyCoupledEKF(max_features=N)
+        g.addNewFeatures(sc.initial_features())
+        for z, R, p in fr[:2]:
+            g.process(sc.dt)
+            assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+        st = g.get_state()
+        for q in where:
+            s0 = 22 + 3 * q
+            st["Sigma"][s0:s0 + 2, s0:s0 + 2] = np.array([[1e-4, 5e-4], [5e-4, 1e-4]], np.float32)  # eigenvalues 6e-4, -4e-4
+        g.set_state(st)
+        g.process(sc.dt)
+        rc = g.updateWithFeaturePositions(*fr[2])
+        assert rc == capi.ENUMERIC, (mode, rc)
+        out[mode] = g.get_state()
+        assert np.isfinite(out[mode]["Sigma"]).all()
+        g.close()
+    for k in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"):
+        assert np.array_equal(out["0"][k], out["2"][k]), k
