@@ -1614,7 +1614,6 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.fin = f->sweep_sync + mb;
         pa.abort_flag = f->sweep_sync + mb + (mb + rb) * mb;
         pa.dbg = f->sweep_dbg;
-        { const char* e = getenv("EKFVIO_PERSIST_DBG"); pa.dbg_mode = e ? atoi(e) : 0; }
         (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * (size_t)(mb + (mb + rb) * mb + 4), f->stream);
         hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
         return;

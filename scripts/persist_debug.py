@@ -29,15 +29,3 @@ for i in range(mb):
 print("X = C S^-1 column blocks: max abs diff", [float(np.abs(X0[:, 64 * j:64 * j + 64] - X2[:, 64 * j:64 * j + 64]).max()) for j in range(mb)])
 print("X row blocks:", [float(np.abs(X0[64 * i:64 * i + 64] - X2[64 * i:64 * i + 64]).max()) for i in range((nr + 63) // 64)])
 
-if int(os.environ.get("EKFVIO_PERSIST_DBG", "0")) & 8:
-    rng = np.random.default_rng(7)
-    Q = rng.standard_normal((m, m))
-    S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
-    for k in range(1, mb - 1):
-        i = k + 1
-        want = S[64 * i:64 * i + 64, 64 * k:64 * k + 64].astype(np.float64)
-        for q in range(k):
-            want -= L0[64 * i:64 * i + 64, 64 * q:64 * q + 64].astype(np.float64) @ L0[64 * k:64 * k + 64, 64 * q:64 * q + 64].T
-        seen = F2[64 * k:64 * k + 64, 64 * i:64 * i + 64]
-        orig = S[64 * i:64 * i + 64, 64 * k:64 * k + 64]
-        print("chain saw tile (%d,%d): vs final %.2e, vs original %.2e" % (i, k, np.abs(seen - want).max(), np.abs(seen - orig).max()))

@@ -1,0 +1,37 @@
+"""In-kernel phase stamps (s_memtime cycles) of the chain workgroup of chol_persist_kernel (EKFVIO_SWEEP=2) during a filter update."""
+import ctypes as C, os, sys
+os.environ.setdefault("EKFVIO_SWEEP", "2")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ekf_vio_amd import TightlyCoupledEKF
+from ekf_vio_amd.sim import Scenario
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+sc = Scenario(N, seed=0)
+g = TightlyCoupledEKF(max_features=N)
+g.addNewFeatures(sc.initial_features())
+g.lib.ekfvio_test_sweep_stamps(g.h, 1, None)
+for z, R, p in sc.frames(6):
+    g.process(sc.dt)
+    g.updateWithFeaturePositions(z, R, p)
+st = (C.c_int64 * 1024)()
+g.lib.ekfvio_test_sweep_stamps(g.h, 1, st)
+v = list(st)
+names = ["operands+wait", "tile requests", "panel solve", "update, block column 0", "factorisation", "stores+publish"]
+mb = (2 * N + 63) // 64
+t0 = v[0]
+for k in range(mb - 1):
+    b = 32 + 8 * k
+    e = [v[b + i] for i in range(6)] + [v[b + 8]]
+    print("step %2d at %6d: " % (k, e[0] - t0) + "  ".join("%s %5d" % (names[i], e[i + 1] - e[i]) for i in range(6))
+          + "   | %6d cycles = %.2f us at 2.4 GHz" % (e[6] - e[0], (e[6] - e[0]) / 2400.0))
+end = v[32 + 8 * (mb - 1)]
+print("chain total %d cycles = %.2f us" % (end - t0, (end - t0) / 2400.0))
+hn = ["wait for ready/fin", "barrier", "loads", "solves", "product", "store+publish"]
+for j in range(2, mb - 1):
+    b = 600 + 8 * j
+    if not v[b]:
+        continue
+    # tile (j+1, j): last step k = j-1 needs ready[j-1] (raised at the top of chain step j-1); the chain asks for it in step j
+    c0 = v[32 + 8 * (j - 1)]
+    print("helper of tile (%d,%d), last step: starts waiting %+6d cycles from the start of chain step %d; " % (j + 1, j, v[b] - c0, j - 1)
+          + "  ".join("%s %5d" % (hn[q], v[b + q + 1] - v[b + q]) for q in range(5)) + "  | published %+6d cycles from that start (chain step %d starts at %+6d)"
+          % (v[b + 5] - c0, j, v[32 + 8 * j] - c0))
