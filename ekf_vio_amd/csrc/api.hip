@@ -215,17 +215,17 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Lsign, (size_t)(f->m_cap / 64 > 256 ? f->m_cap / 64 : 256)));  // 256: the raw-solve test hook goes up to m = 16384
-    {   // flags of the persistent sweeps: mode 1: 2 mb + 4 words; mode 2: ready[mb] + fin[row blocks x mb] + 4 (used below 16 block columns)
-        const size_t mbc = (size_t)(f->m_cap / 64 > 128 ? f->m_cap / 64 : 128);
+    {   // flags of the persistent sweep (chol_persist.inc): ready[mb] + fin[row blocks x mb] + abort word, below 16 block columns
         const size_t mb2 = (size_t)std::min(f->m_cap / 64, 16);
-        HIPC(f, dev_alloc(f->stream, &f->sweep_sync, std::max(2 * mbc + 4, mb2 + (size_t)(f->ld_aug / 64 + 1) * mb2 + 8)));
+        f->sweep_sync_words = std::max((size_t)1024, mb2 + (size_t)(f->ld_aug / 64 + 1) * mb2 + 8);  // (>= 1024: the test hooks sweep matrices that are not the filter's)
+        HIPC(f, dev_alloc(f->stream, &f->sweep_sync, f->sweep_sync_words));
     }
     {
         hipDeviceProp_t prop;
         HIPC(f, hipGetDeviceProperties(&prop, device));
         f->num_cus = prop.multiProcessorCount;
         const char* e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
-        if (e) f->sweep_mode = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
+        if (e) f->sweep_mode = atoi(e) ? 2 : 0;
         e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_SCHUR");  // tuning knob: 1 = Sigma (I - K H)^T and K as Schur tiles inside the sweep instead of two GEMMs behind it
@@ -943,6 +943,14 @@ int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const 
         HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
     }
     HIPC(f, hipStreamSynchronize(f->stream));
+    if (const char* dp = getenv("EKFVIO_DEBUG_DUMP_LAUG")) {  // diagnostic: the whole swept matrix [L; Y; L^-T]
+        if (FILE* fp = fopen(dp, "wb")) {
+            const int hdr[3] = {ld, mp, rp};
+            fwrite(hdr, sizeof(int), 3, fp);
+            fwrite(hl.data(), sizeof(float), hl.size(), fp);
+            fclose(fp);
+        }
+    }
     if (L_out)
         for (int c = 0; c < m; c++)
             for (int r = 0; r < m; r++) L_out[(size_t)c * m + r] = (r >= c) ? hl[(size_t)c * ld + r] : 0.f;

@@ -488,8 +488,15 @@ __device__ __forceinline__ void potrf_inverse16(const float* A, float* Tinv, int
 // idle(integral_constant<p>, wave): called by wavefronts 1-3 in phase F of panel p after their own share of it.  Columns
 // left of panel p and the inverses of the blocks before p are final by then (read-only for everyone): a caller can have
 // them stored while the chain runs (waves 2-3 are free in phase F of panel 2, waves 1-3 in that of panel 3).
-template <int FV = EKF_POTRF_FV, class Idle = NoIdleWork>
+// RAW_BARRIER: the barriers wait for this wavefront's LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier) instead of
+// __syncthreads(), which also drains its global loads: an idle hook can then leave loads in flight across phases.
+template <int FV = EKF_POTRF_FV, class Idle = NoIdleWork, bool RAW_BARRIER = false>
 __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long long* stamps = nullptr, Idle idle = Idle()) {
+#define POTRF_BAR()                                                                                  \
+    do {                                                                                             \
+        if constexpr (RAW_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+        else __syncthreads();                                                                        \
+    } while (0)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     bool bad = false;
@@ -575,13 +582,13 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
         }
         if (wave != 0) idle(pc, wave);
         POTRF_WSTAMP(2 * p);
-        __syncthreads();
+        POTRF_BAR();
         POTRF_STAMP(2 + 2 * p);
         // ---- phase C: panel p's update of the next panel's columns (tiles (ti,0)) ----
         if (p < 3) {
             if (wave < 3 - p) potrf_tile_update(A, c0, wave, 0, lane);
             POTRF_WSTAMP(2 * p + 1);
-            __syncthreads();
+            POTRF_BAR();
         }
         POTRF_STAMP(3 + 2 * p);
     });
@@ -590,6 +597,7 @@ __device__ __forceinline__ bool potrf64_lds(float* A, float* Tinv, int tid, long
     // every wavefront looks at the 64 diagonal entries itself: the answer is uniform over the workgroup without a barrier
     bad = __ballot(!(A[lane * PLD + lane] > 2e-10f)) != 0ull;
     return bad;
+#undef POTRF_BAR
 }
 
 // Slow path for a tile the fast factorisation flagged (see the header): A = U S U^T by plain right-looking column
@@ -1287,263 +1295,8 @@ __global__ __launch_bounds__(256) void sign_irows_kernel(float* __restrict__ L, 
 }
 
 
-// ---- agent-coherent tile movers for the persistent sweep ---------------------------------
-// The eight XCDs have private L2s; data handed from one workgroup to another inside a running
-// kernel must bypass them.  Agent-scope relaxed atomic accesses compile to sc1 loads/stores
-// (write-through / read from the coherence point), 8 bytes per lane, and need no L2
-// write-back or invalidate (a __threadfence here costs ~10 us: buffer_wbl2 of the whole L2).
-__device__ __forceinline__ float2 coh_load2(const float* p) {
-    const unsigned long long u =
-        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-}
-__device__ __forceinline__ void coh_store2(float* p, float a, float b) {
-    const unsigned long long u = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void load_tile_coh(float* T, const float* G, int ld, int tid) {
-    float2 v[8];
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int e = tid + it * 256;
-        v[it] = coh_load2(G + (size_t)(e >> 5) * ld + (e & 31) * 2);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int e = tid + it * 256;
-        float* t = T + (e >> 5) * PLD + (e & 31) * 2;
-        t[0] = v[it].x; t[1] = v[it].y;
-    }
-}
-template <bool LOWER>
-__device__ __forceinline__ void store_tile_coh(const float* T, float* G, int ld, int tid) {
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int e = tid + it * 256;
-        const int c = e >> 5, r2 = (e & 31) * 2;
-        const float* t = T + c * PLD + r2;
-        coh_store2(G + (size_t)c * ld + r2, (!LOWER || r2 >= c) ? t[0] : 0.f, (!LOWER || r2 + 1 >= c) ? t[1] : 0.f);
-    }
-}
-__device__ __forceinline__ void load_inv_coh(float* Tinv, const float* G, int tid) {
-#pragma unroll
-    for (int h2 = 0; h2 < 2; h2++) {
-        const int e = (tid * 2 + h2) * 2;  // float index of a pair
-        const float2 v = coh_load2(G + e);
-        const int p = e >> 8, c = (e >> 4) & 15, r = e & 15;
-        Tinv[p * 16 * ILD + c * ILD + r] = v.x;
-        Tinv[p * 16 * ILD + c * ILD + r + 1] = v.y;
-    }
-}
-__device__ __forceinline__ void store_inv_coh(const float* Tinv, float* G, int tid) {
-#pragma unroll
-    for (int h2 = 0; h2 < 2; h2++) {
-        const int e = (tid * 2 + h2) * 2;
-        const int p = e >> 8, c = (e >> 4) & 15, r = e & 15;
-        coh_store2(G + e, Tinv[p * 16 * ILD + c * ILD + r], Tinv[p * 16 * ILD + c * ILD + r + 1]);
-    }
-}
-
-// ---- the whole sweep as ONE persistent launch -------------------------------------------
-// Workgroup 0 is the chain: it keeps L_kk and its 16x16 inverses in LDS from one block step to
-// the next, forms L_{k+1,k}, updates the next diagonal tile and factors it, and never leaves
-// the CU.  The other workgroups ("helpers") do the trailing tiles of step k as soon as
-// ready[k] is published.  Cross-workgroup ordering goes through two counters per block step
-// in global memory:
-//   ready[k] = 1      L_kk and its inverses are in global memory          (chain -> helpers)
-//   done[k]  = H      every helper has applied step k to all of its tiles (helpers -> all)
-// Helper h needs done[k-1] == H before touching step k because the panel blocks it reads were
-// updated by other helpers in step k-1; the chain needs it for tiles (k+1,k) and (k+1,k+1).
-// While the chain factors the next diagonal tile (about 6 us) the helpers finish step k (about
-// 3 us at N = 256), so in steady state nobody waits.  All waits are bounded: a wait that
-// exceeds SWEEP_SPIN_LIMIT polls raises the abort flag, after which every wait falls through
-// (the result is then garbage and info bit 1 is set), so the grid always drains.
-// Requires gridDim.x <= number of CUs (one resident workgroup per CU).
+// every wait inside the persistent sweep is bounded by this many polls (chol_persist.inc)
 #define SWEEP_SPIN_LIMIT (1 << 22)
-
-
-__device__ __forceinline__ void sweep_wait(int* flag, int target, int* abort_flag, int* info, int tid) {
-    if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SWEEP_SPIN_LIMIT) {
-                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicOr(info, 2);
-                break;
-            }
-        }
-    }
-    __syncthreads();  // the coherent loads that follow are issued after the flag was seen
-}
-// every thread's coherent stores have completed (vmcnt 0) before the flag moves
-__device__ __forceinline__ void sweep_signal_set(int* flag, int tid) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sweep_signal_add(int* flag, int tid) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(256) void chol_sweep_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
-                                                         float* __restrict__ Linv, int mb, int rb, int idb0, int* info,
-                                                         int* sync, long long* dbg) {
-    __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];
-    __shared__ __attribute__((aligned(16))) float Tj[PB * PLD];
-    __shared__ __attribute__((aligned(16))) float Tl[PB * PLD];
-    __shared__ float Tinv[INV_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave & 1, wc = wave >> 1;
-    const int H = gridDim.x - 1;
-    int* ready = sync;
-    int* done = sync + mb;
-    int* abort_flag = sync + 2 * mb;
-    const int r = wr * 32 + (lane & 31);
-
-#define SWEEP_STAMP(slot)                                                                      \
-    do {                                                                                       \
-        if (dbg && tid == 0) dbg[(slot)] = (long long)__builtin_amdgcn_s_memtime();            \
-    } while (0)
-#define SWEEP_RSTAMP(slot) /* 100 MHz clock shared by all XCDs (s_memtime is per XCD) */     \
-    do {                                                                                       \
-        if (dbg && tid == 0) dbg[(slot)] = (long long)__builtin_amdgcn_s_memrealtime();        \
-    } while (0)
-    if (blockIdx.x == 0) {
-        // ---------------- chain ----------------
-        SWEEP_STAMP(0);
-        load_tile_coh(Tl, S, lds, tid);
-        __syncthreads();
-        bool bad = potrf64_lds(Tl, Tinv, tid);
-        store_tile_coh<true>(Tl, L, ldl, tid);
-        store_inv_coh(Tinv, Linv, tid);
-        sweep_signal_set(ready + 0, tid);
-        SWEEP_STAMP(1);
-        for (int k = 0; k + 1 < mb; k++) {
-            SWEEP_STAMP(8 + 8 * k + 0);
-            if (k >= 1) sweep_wait(done + (k - 1), H, abort_flag, info, tid);
-            SWEEP_STAMP(8 + 8 * k + 1);
-            const int i = k + 1;
-            // the next diagonal tile's coherent loads fly while the panel block is solved
-            const float* Sii = S + (size_t)i * PB * lds + (size_t)i * PB;
-            float sv[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                sv[q] = __hip_atomic_load(Sii + (size_t)c * lds + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            load_tile_coh(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
-            __syncthreads();
-            SWEEP_STAMP(8 + 8 * k + 2);
-            tri_solve_fwd(Ti, Tl, Tinv, wave, lane);  // L_ik = A_ik L_kk^-T, L_kk still in LDS
-            __syncthreads();
-            SWEEP_STAMP(8 + 8 * k + 3);
-            store_tile_coh<false>(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
-            const f32x16 up = mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane);
-            __syncthreads();  // every wave is done reading Tl (L_kk) before it is overwritten
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                Tl[c * PLD + r] = sv[q] - up[q];
-            }
-            __syncthreads();
-            SWEEP_STAMP(8 + 8 * k + 4);
-            bad |= potrf64_lds(Tl, Tinv, tid);
-            SWEEP_STAMP(8 + 8 * k + 5);
-            store_tile_coh<true>(Tl, L + (size_t)i * PB * ldl + (size_t)i * PB, ldl, tid);
-            store_inv_coh(Tinv, Linv + (size_t)i * PB * PB, tid);
-            sweep_signal_set(ready + i, tid);
-            SWEEP_STAMP(8 + 8 * k + 6);
-            SWEEP_RSTAMP(1008 + k);
-        }
-        if (bad && tid == 0) atomicOr(info, 1);
-        return;
-    }
-
-    // ---------------- helpers ----------------
-    const int h = blockIdx.x - 1;
-    for (int k = 0; k < mb; k++) {
-        const int rr = mb - 1 - k, ntri = rr * (rr + 1) / 2;
-        const int ntiles = (rr > 0) ? ntri + rb * rr : rb;
-        if (h == 1) SWEEP_STAMP(256 + 8 * k + 0);
-        if (k >= 1) sweep_wait(done + (k - 1), H, abort_flag, info, tid);
-        if (h == 1) SWEEP_STAMP(256 + 8 * k + 1);
-        bool have_L = false;  // L_kk and its inverses are fetched after the first tile's own loads are in flight
-        for (int t0 = h; t0 < ntiles; t0 += H) {
-            int t = t0, i, j;
-            if (rr == 0) {  // last block column: only the extra row blocks' panel solve is left
-                i = mb + t;
-                __syncthreads();
-                load_tile_coh(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
-                if (!have_L) {
-                    sweep_wait(ready + k, 1, abort_flag, info, tid);
-                    load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);  // write-once data: L2 is safe
-                    load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
-                    have_L = true;
-                }
-                __syncthreads();
-                tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
-                __syncthreads();
-                store_tile_coh<false>(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
-                continue;
-            }
-            if (t < ntri) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-                i = k + 1 + ii;
-                j = k + 1 + (t - ii * (ii + 1) / 2);
-                if (i == k + 1) continue;  // (k+1,k+1) belongs to the chain
-            } else {
-                t -= ntri;
-                i = mb + t / rr;
-                j = k + 1 + t % rr;
-                if (i >= idb0 && i - idb0 > k) continue;  // identity block row: block (i,k) is still zero
-            }
-            __syncthreads();  // previous tile's readers of Ti/Tj are done
-            load_tile_coh(Ti, S + (size_t)k * PB * lds + (size_t)i * PB, lds, tid);
-            if (i != j) load_tile_coh(Tj, S + (size_t)k * PB * lds + (size_t)j * PB, lds, tid);
-            float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
-            float sv[16];  // the target tile's coherent loads fly during the panel solves
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                sv[q] = __hip_atomic_load(Sij + (size_t)c * lds + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (!have_L) {
-                sweep_wait(ready + k, 1, abort_flag, info, tid);
-                // L_kk and its inverses are written once (by the chain, write-through) and first read after
-                // ready[k]: no XCD can hold a stale copy, so these go through the L2 -- 170 helpers
-                // pulling the same 20 KB past the L2 is a fabric hot spot (measured: 10 us per step)
-                load_tile(Tl, L + (size_t)k * PB * ldl + (size_t)k * PB, ldl, tid);
-                load_inv(Tinv, Linv + (size_t)k * PB * PB, tid);
-                have_L = true;
-                if (h == 1) SWEEP_STAMP(256 + 8 * k + 2);
-                if (k == 2 && h < 240) SWEEP_RSTAMP(768 + h);
-            }
-            __syncthreads();
-            if (i != j)
-                tri_solve_fwd2(Ti, Tj, Tl, Tinv, wave, lane);
-            else
-                tri_solve_fwd(Ti, Tl, Tinv, wave, lane);
-            __syncthreads();
-            if (j == k + 1) store_tile_coh<false>(Ti, L + (size_t)k * PB * ldl + (size_t)i * PB, ldl, tid);
-            const float* Bj = (i != j) ? Tj : Ti;
-            const f32x16 up = mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane);
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                __hip_atomic_store(Sij + (size_t)c * lds + r, sv[q] - up[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if (h == 1) SWEEP_STAMP(256 + 8 * k + 3);
-        if (k == 2 && h < 240) SWEEP_RSTAMP(512 + h);
-        if (k + 1 < mb) sweep_signal_add(done + k, tid);
-        if (h == 1) SWEEP_STAMP(256 + 8 * k + 4);
-    }
-}
 
 #include "chol_persist.inc"
 
@@ -1581,7 +1334,9 @@ static int persist_helpers(int mb, int nX) {
 }
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
-    return f->sweep_mode == 2 && mb >= 2 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus;
+    const int rows = 2 * mb + n_pad / PB;
+    return f->sweep_mode == 2 && mb >= 2 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
+           (size_t)(3 * mb + rows * mb + 4) <= f->sweep_sync_words;
 }
 
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done,
@@ -1591,17 +1346,6 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int mb = m_pad / PB;
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
     const int idb0 = mb + n_pad / PB;
-    if (f->sweep_mode == 1) {
-        // one persistent launch; the grid must be co-resident (<= one workgroup per CU)
-        const int r0 = mb - 1;
-        const int tiles0 = r0 > 0 ? r0 * (r0 + 1) / 2 + rb * r0 : rb;
-        int helpers = tiles0 < f->num_cus - 1 ? tiles0 : f->num_cus - 1;
-        if (helpers < 1) helpers = 1;
-        (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * (2 * mb + 4), f->stream);
-        hipLaunchKernelGGL(chol_sweep_kernel, dim3(1 + helpers), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb, rb,
-                           idb0, f->info, f->sweep_sync, f->sweep_dbg);
-        return;
-    }
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     if (!schur && sweep_is_persistent(f, m_pad, n_pad)) {
@@ -1614,7 +1358,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.fin = f->sweep_sync + mb;
         pa.abort_flag = f->sweep_sync + mb + (mb + rb) * mb;
         pa.dbg = f->sweep_dbg;
-        (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * (size_t)(mb + (mb + rb) * mb + 4), f->stream);
+        const size_t words = ((size_t)(mb + (mb + rb) * mb + 1) + 3) & ~(size_t)3;  // (a multiple of 16 bytes)
+        (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * words, f->stream);
         hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
         return;
     }

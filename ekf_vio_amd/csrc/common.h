@@ -98,9 +98,10 @@ struct ekfvio_filter {
     int ld_aug = 0;            // m_cap + ldp + m_cap
     float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
     unsigned long long* Lsign = nullptr;  // [>= m_cap/64] per block column: mask of negative pivots (0 = positive definite block)
-    int* sweep_sync = nullptr; // [2*m_cap/64 + 4] ready/done counters + abort flag of the persistent sweep
-    int sweep_mode = 0;        // 0: one launch per block step; 1: round 1's persistent launch (chol_sweep_kernel); 2: the persistent
-                               // launch with per-tile hand-offs (chol_persist.inc)
+    int* sweep_sync = nullptr; // flags of the persistent sweep: ready[mb], fin[row blocks x mb], abort word (sweep_sync_words ints)
+    int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it
+                               // applies (2 .. 15 block columns, grid co-resident); 0 (EKFVIO_SWEEP=0): one launch per block step
+    size_t sweep_sync_words = 0;
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
     int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.

@@ -946,7 +946,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     // T = Sigma - X A^-1 X^T and K = X A^-1 as Schur tiles of the sweep (no gain GEMM, no first Joseph GEMM, no (H Sigma)^T)
     const bool schur = m > 0 && sweep_supports_schur(f, m_pad);
     bool fused_gather = false;
-    if (m > 0 && f->sweep_mode != 1 && f->fuse_gather) {
+    if (m > 0 && f->fuse_gather) {
         const int gx = (std::max(ld, m_pad) + 255) / 256;
         fused_gather = 1 + gx * ((m_pad + GC * GCI - 1) / (GC * GCI)) + (schur ? 0 : (m_pad / 64) * (ld / 64)) <= f->num_cus;
     }

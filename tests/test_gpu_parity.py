@@ -440,33 +440,33 @@ def test_profile_update_gemms_leaves_state_untouched():
 
 
 def test_persistent_sweep_matches_per_step_sweep(monkeypatch):
-    """EKFVIO_SWEEP=1 selects the single-launch sweep (chain workgroup + helpers handing tiles over through
-    write-through stores and flags): same device functions in the same order, so the same bits as one launch per
-    block step, for the raw factorisation and for a filter update."""
+    """The single-launch sweep (the default; chol_persist.inc) against one launch per block step (EKFVIO_SWEEP=0): same
+    device functions in the same order, so the same bits, for the raw factorisation with its right-hand sides and for a
+    filter update."""
     rng = np.random.default_rng(7)
-    m, nr = 200, 150
-    Q = rng.standard_normal((m, m))
-    S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
-    Cr = rng.standard_normal((nr, m)).astype(np.float32)
     N = 48
     sc = Scenario(N, seed=2)
     fr = list(sc.frames(3))
-    res = []
     monkeypatch.setenv("EKFVIO_SCHUR", "0")  # the persistent sweep has no Schur tiles: compare like with like
-    for mode in ("0", "1"):
-        monkeypatch.setenv("EKFVIO_SWEEP", mode)
-        g = TightlyCoupledEKF(max_features=N)
-        L, X, info = g.test_cholesky_solve(S, Cr)
-        assert info == 0
-        g.addNewFeatures(sc.initial_features())
-        for z, R, p in fr:
-            g.process(sc.dt)
-            assert g.updateWithFeaturePositions(z, R, p) == capi.OK
-        res.append((np.tril(L), X, g.get_state()))
-        g.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    for key in ("base_mu", "feat_mu", "Sigma"):
-        assert np.array_equal(res[0][2][key], res[1][2][key]), key
+    for m, nr in ((200, 150), (128, 100), (192, 64), (512, 790), (960, 300)):
+        Q = rng.standard_normal((m, m))
+        S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
+        Cr = rng.standard_normal((nr, m)).astype(np.float32)
+        res = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("EKFVIO_SWEEP", mode)
+            g = TightlyCoupledEKF(max_features=N)
+            L, X, info = g.test_cholesky_solve(S, Cr)
+            assert info == 0
+            g.addNewFeatures(sc.initial_features())
+            for z, R, p in fr:
+                g.process(sc.dt)
+                assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+            res.append((np.tril(L), X, g.get_state()))
+            g.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (m, nr)
+        for key in ("base_mu", "feat_mu", "Sigma"):
+            assert np.array_equal(res[0][2][key], res[1][2][key]), key
 
 
 def test_launch_fusion_knobs_do_not_change_bits(monkeypatch):
@@ -574,10 +574,10 @@ def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
 
 @pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (100, 3), (64, 0), (40, 5), (33, 0)])
 def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkeypatch, N, fails):
-    """EKFVIO_SWEEP=2 (chol_persist.inc): everything behind the first diagonal tile in ONE launch -- the chain workgroup
+    """The default sweep (chol_persist.inc): everything behind the first diagonal tile in ONE launch -- the chain workgroup
     keeps L_kk in LDS from step to step, every other tile has an owner workgroup that keeps it in registers for the whole
     sweep, hand-offs are write-through stores behind per-tile flags.  Same per-tile arithmetic in the same order as one
-    launch per block step: every bit of the state must agree, per call and in graph replay, with ragged measurement
+    launch per block step (EKFVIO_SWEEP=0): every bit of the state must agree, per call and in graph replay, with ragged measurement
     counts and with one, two, four and eight block columns."""
     sc = Scenario(N, seed=11)
     fr = list(sc.frames(5))
@@ -610,8 +610,8 @@ def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkey
 @pytest.mark.parametrize("where", [(3,), (40,), (3, 40, 70, 120)])
 def test_persistent_per_tile_sweep_through_the_signed_factorisation(monkeypatch, where):
     """The rare path inside the persistent sweep: a diagonal tile that meets a non-positive pivot is factored again as
-    U S U^T and its sign mask travels with ready[k] to every helper (round 1's persistent sweep had no signed
-    path).  The covariance gets an indefinite 2x2 (u, v) block for the landmarks in `where` (landmark q's rows are
+    U S U^T and its sign mask travels with ready[k] to every helper (round 1's persistent sweep, since removed,
+    had no signed path).  The covariance gets an indefinite 2x2 (u, v) block for the landmarks in `where` (landmark q's rows are
     measurement rows 2q, 2q+1: the first launch's tile for q < 32, the sweep's steps beyond).  Both forms of the sweep
     must flag it and agree bit for bit."""
     N = 128
