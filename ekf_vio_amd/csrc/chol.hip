@@ -689,6 +689,10 @@ __global__ __launch_bounds__(256) void gather_potrf_kernel(GatherArgs ga, float*
         if (dbg && tid == 0) dbg[1000 + (slot)] = (long long)__builtin_amdgcn_s_memtime();          \
     } while (0)
     if (blockIdx.x != 0) {
+        // the flags of the persistent sweep behind this launch: zeroed here (a memset node between the two launches cost
+        // 4.9 us of every filter step)
+        if (blockIdx.x == gridDim.x - 1 && ga.zero_words)
+            for (int e = tid; e < ga.n_zero; e += 256) ga.zero_words[e] = 0;
         gather_body(ga, (int)blockIdx.x - 1, dyn_lds);
         if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) dbg[1004] = (long long)__builtin_amdgcn_s_memtime();
         if (dbg && tid == 0 && blockIdx.x == 1) dbg[1005] = (long long)__builtin_amdgcn_s_memtime();
@@ -1311,6 +1315,10 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps, (w && atoi(w)) ? 2 : 1);
 }
 
+static size_t persist_flag_words(int m_pad, int n_pad) {  // ready[mb] + fin[row blocks x mb] + abort word, a multiple of 16 bytes
+    const int mb = m_pad / PB, rows = 2 * mb + n_pad / PB;
+    return ((size_t)(mb + rows * mb + 1) + 3) & ~(size_t)3;
+}
 #define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, bool with_wt) {
     if (!f->gather_attr_set) {
@@ -1320,6 +1328,11 @@ void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_o
     }
     GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
     if (m_on_device) ga.m_dev = f->info + 2;
+    if (sweep_is_persistent(f, m_pad, n_pad)) {
+        ga.zero_words = f->sweep_sync;
+        ga.n_zero = (int)persist_flag_words(m_pad, n_pad);
+        f->sweep_flags_zeroed = true;  // (launch_chol_sweep, called next, skips its memset)
+    }
     const int nb2 = with_wt ? (m_pad / 64) * (f->ldp / 64) : 0;  // 64x64 transposing tiles of Wt (only the first Joseph GEMM reads it)
     hipLaunchKernelGGL(gather_potrf_kernel, dim3(1 + ga.nb1 + nb2), dim3(256), EKF_GATHER_POTRF_LDS, f->stream, ga, f->Laug, f->ld_aug,
                        f->Linv, f->info, f->Lsign, f->sweep_dbg);
@@ -1336,7 +1349,7 @@ bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     const int rows = 2 * mb + n_pad / PB;
     return f->sweep_mode == 2 && mb >= 2 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
-           (size_t)(3 * mb + rows * mb + 4) <= f->sweep_sync_words;
+           persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
 }
 
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done,
@@ -1346,6 +1359,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int mb = m_pad / PB;
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
     const int idb0 = mb + n_pad / PB;
+    const bool flags_zeroed = f->sweep_flags_zeroed;  // (by gather_potrf_kernel, the launch in front, in the filter's update)
+    f->sweep_flags_zeroed = false;
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     if (!schur && sweep_is_persistent(f, m_pad, n_pad)) {
@@ -1358,8 +1373,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.fin = f->sweep_sync + mb;
         pa.abort_flag = f->sweep_sync + mb + (mb + rb) * mb;
         pa.dbg = f->sweep_dbg;
-        const size_t words = ((size_t)(mb + (mb + rb) * mb + 1) + 3) & ~(size_t)3;  // (a multiple of 16 bytes)
-        (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * words, f->stream);
+        if (!flags_zeroed) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
         hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
         return;
     }

@@ -102,6 +102,7 @@ struct ekfvio_filter {
     int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it
                                // applies (2 .. 15 block columns, grid co-resident); 0 (EKFVIO_SWEEP=0): one launch per block step
     size_t sweep_sync_words = 0;
+    bool sweep_flags_zeroed = false;  // gather_potrf_kernel has zeroed the flags for the sweep launch enqueued next
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
     int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.

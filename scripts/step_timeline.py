@@ -10,9 +10,11 @@ ev.sort()
 starts = [i for i, e in enumerate(ev) if e[2].startswith("predict_fused_kernel")]
 if len(starts) < 40:
     print("too few steps", len(starts)); sys.exit(0)
-# steps of the last graph replay, away from its ends
-steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 20, len(starts) - 4)]
-n = steps[0][1] - steps[0][0]
+# steps from the middle of the run (the timed graph replays; the bench's last steps are its eager, per-stage timed ones)
+mid = len(starts) // 2
+steps = [(starts[i], starts[i + 1]) for i in range(mid - 8, mid + 8)]
+import collections
+n = collections.Counter(b - a for a, b in steps).most_common(1)[0][0]
 steps = [s for s in steps if s[1] - s[0] == n]
 per = statistics.median((ev[b][0] - ev[a][0]) / 1e3 for a, b in steps)
 print("%d kernels per step, median step period %.2f us over %d steps" % (n, per, len(steps)))
