@@ -1348,7 +1348,7 @@ static int persist_helpers(int mb, int nX) {
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     const int rows = 2 * mb + n_pad / PB;
-    return f->sweep_mode == 2 && mb >= 2 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
+    return f->sweep_mode == 2 && mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
            persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
 }
 

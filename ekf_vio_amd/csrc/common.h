@@ -99,8 +99,8 @@ struct ekfvio_filter {
     float* Linv = nullptr;     // [64*m_cap] inverses of the 16x16 diagonal blocks of L
     unsigned long long* Lsign = nullptr;  // [>= m_cap/64] per block column: mask of negative pivots (0 = positive definite block)
     int* sweep_sync = nullptr; // flags of the persistent sweep: ready[mb], fin[row blocks x mb], abort word (sweep_sync_words ints)
-    int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it
-                               // applies (2 .. 15 block columns, grid co-resident); 0 (EKFVIO_SWEEP=0): one launch per block step
+    int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it pays and
+                               // applies (3 .. 15 block columns, grid co-resident; two block columns: 43.5 against 43.0 us per step); 0 (EKFVIO_SWEEP=0): one launch per block step
     size_t sweep_sync_words = 0;
     bool sweep_flags_zeroed = false;  // gather_potrf_kernel has zeroed the flags for the sweep launch enqueued next
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)

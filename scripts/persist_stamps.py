@@ -15,7 +15,7 @@ for z, R, p in sc.frames(6):
 st = (C.c_int64 * 1024)()
 g.lib.ekfvio_test_sweep_stamps(g.h, 1, st)
 v = list(st)
-names = ["operands+wait", "tile requests", "panel solve", "update, block column 0", "factorisation", "stores+publish"]
+names = ["operands, look, tile requests, publish", "pin", "panel solve", "update, block column 0", "factorisation", "stores"]
 mb = (2 * N + 63) // 64
 t0 = v[0]
 for k in range(mb - 1):
@@ -35,3 +35,4 @@ for j in range(2, mb - 1):
     print("helper of tile (%d,%d), last step: starts waiting %+6d cycles from the start of chain step %d; " % (j + 1, j, v[b] - c0, j - 1)
           + "  ".join("%s %5d" % (hn[q], v[b + q + 1] - v[b + q]) for q in range(5)) + "  | published %+6d cycles from that start (chain step %d starts at %+6d)"
           % (v[b + 5] - c0, j, v[32 + 8 * j] - c0))
+print("wavefront 0's early look at the step's two flags (100 = both up, 101 = not yet):", [int(v[500 + k]) for k in range(1, mb - 1)])
