@@ -25,14 +25,10 @@ for k in range(mb - 1):
           + "   | %6d cycles = %.2f us at 2.4 GHz" % (e[6] - e[0], (e[6] - e[0]) / 2400.0))
 end = v[32 + 8 * (mb - 1)]
 print("chain total %d cycles = %.2f us" % (end - t0, (end - t0) / 2400.0))
-hn = ["wait for ready/fin", "barrier", "loads", "solves", "product", "store+publish"]
+hn = ["waits for ready / fin", "loads (one round trip) + barrier", "substitutions", "product", "tile -> LDS, store, publish"]
 for j in range(2, mb - 1):
     b = 600 + 8 * j
-    if not v[b]:
-        continue
-    # tile (j+1, j): last step k = j-1 needs ready[j-1] (raised at the top of chain step j-1); the chain asks for it in step j
-    c0 = v[32 + 8 * (j - 1)]
-    print("helper of tile (%d,%d), last step: starts waiting %+6d cycles from the start of chain step %d; " % (j + 1, j, v[b] - c0, j - 1)
-          + "  ".join("%s %5d" % (hn[q], v[b + q + 1] - v[b + q]) for q in range(5)) + "  | published %+6d cycles from that start (chain step %d starts at %+6d)"
-          % (v[b + 5] - c0, j, v[32 + 8 * j] - c0))
+    if v[b]:  # (these run on other XCDs: their s_memtime counters have other origins, only differences mean something)
+        print("helper of tile (%d,%d), its last step (what the chain's step %d waits for): " % (j + 1, j, j)
+              + "  ".join("%s %5d" % (hn[q], v[b + q + 1] - v[b + q]) for q in range(5)))
 print("wavefront 0's early look at the step's two flags (100 = both up, 101 = not yet):", [int(v[500 + k]) for k in range(1, mb - 1)])
