@@ -483,6 +483,17 @@ def main():
         except Exception as ex:  # diagnostic extra, never fatal
             extra["roofline_stress_shape"] = {"error": str(ex)}
         extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
+        # The sweep is the longest launch of the step (half of it at N=256), and it is NOT the roofline kernel: its duration is
+        # the latency of one workgroup's sequential pivot chain, stated here so that nobody has to infer it
+        if "cholesky" in extra["stage_us_per_step"]:
+            us_sweep = extra["stage_us_per_step"]["cholesky"]
+            extra["roofline_sweep"] = {"bound": "latency (sequential pivot chain of one workgroup; DESIGN.md section 3)",
+                                       "kernel": "Cholesky sweep behind the first diagonal tile (chol_persist_kernel where it applies, else one launch per block step)",
+                                       "flops_per_step": fl["cholesky_sweep"], "stage_us": us_sweep,
+                                       "achieved": fl["cholesky_sweep"] / (us_sweep * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": fl["cholesky_sweep"] / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       "note": "event-bracketed stage time of the eager, per-stage timed run (includes a few us of launch gaps); "
+                                               "in-kernel stamps: profiles/r03_cholesky_phase_stamps.txt"}
     g.close()
     if rank == 0 and world == 1 and not args.no_full_loop:
         try:

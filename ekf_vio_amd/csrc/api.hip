@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 
 #include "common.h"
@@ -261,6 +262,17 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     return ekfvio_reset(f);
 }
 
+}  // extern "C"
+
+// Live handles per device in this process.  The persistent sweep needs all its workgroups resident together; two such
+// launches from different handles' streams can each get part of the compute units and wait for workgroups the other one
+// keeps out (every wait is bounded, but that ends in an aborted update, not in a result).  It is therefore used only by
+// a device's sole handle; with several handles on a device every one of them takes one launch per block step.
+static std::atomic<int> g_live_handles[64];
+int live_handles_on(int device) { return (device >= 0 && device < 64) ? g_live_handles[device].load(std::memory_order_relaxed) : 2; }
+
+extern "C" {
+
 int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out) {
     if (!out) return EKFVIO_EINVAL;
     *out = nullptr;
@@ -270,6 +282,7 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     ekfvio_filter* f = new ekfvio_filter();
     f->cfg = *cfg;
     f->device = device;
+    if (device < 64) g_live_handles[device].fetch_add(1, std::memory_order_relaxed);
     const int rc = create_body(f, cfg, device, stream);
     if (rc != EKFVIO_OK) {
         // a half-built handle never leaves the library: whatever was allocated is released here
@@ -300,6 +313,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
+    if (f->device >= 0 && f->device < 64) g_live_handles[f->device].fetch_sub(1, std::memory_order_relaxed);
     delete f;
     return EKFVIO_OK;
 }
@@ -655,7 +669,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
         // by value (a copy from a host scalar could be overtaken by the next call's write to that scalar)
         HIPC(f, hipMemsetD32Async((hipDeviceptr_t)counter, first % f->seq_frames, 1, f->stream));
         if (!f->step_graph || f->graph_N != f->N || f->graph_m != m || f->graph_dt != dt || f->graph_mu != f->mu || f->graph_P != f->P ||
-            f->graph_seq != f->seq_z || f->graph_frames != f->seq_frames) {
+            f->graph_seq != f->seq_z || f->graph_frames != f->seq_frames || f->graph_sole != (live_handles_on(f->device) <= 1)) {
             drop_graph(f);
             int rc = capture_steps(f, EKF_GRAPH_STEPS, m, dt, counter, &f->step_graph);
             if (rc != EKFVIO_OK) return rc;
@@ -663,6 +677,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
             if (rc != EKFVIO_OK) return rc;
             f->graph_N = f->N; f->graph_m = m; f->graph_dt = dt; f->graph_mu = f->mu; f->graph_P = f->P; f->graph_seq = f->seq_z;
             f->graph_frames = f->seq_frames;
+            f->graph_sole = live_handles_on(f->device) <= 1;  // (decides which sweep the captured steps contain)
             // the captured launches did not execute: the pointer swaps of launch_predict netted to zero
         }
         // captured together with the short graph (i.e. in a caller's warm-up call) whenever the uploaded sequence is
@@ -902,6 +917,12 @@ int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t* stamps /* [1
         HIPC(f, hipMemcpyAsync(stamps, f->sweep_dbg, 1024 * sizeof(long long), hipMemcpyDeviceToHost, f->stream));
         HIPC(f, hipStreamSynchronize(f->stream));
     }
+    return EKFVIO_OK;
+}
+
+int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count) {
+    if (!f || !count) return EKFVIO_EINVAL;
+    *count = f->persistent_sweeps;
     return EKFVIO_OK;
 }
 

@@ -1348,7 +1348,8 @@ static int persist_helpers(int mb, int nX) {
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     const int rows = 2 * mb + n_pad / PB;
-    return f->sweep_mode == 2 && mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
+    // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
+    return f->sweep_mode == 2 && live_handles_on(f->device) <= 1 && mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
            persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
 }
 
@@ -1375,6 +1376,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.dbg = f->sweep_dbg;
         if (!flags_zeroed) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
         hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
+        f->persistent_sweeps++;
         return;
     }
     // many tiles per step: panel blocks once per step in a launch of their own instead of twice per tile

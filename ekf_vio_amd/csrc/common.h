@@ -102,6 +102,7 @@ struct ekfvio_filter {
     int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it pays and
                                // applies (3 .. 15 block columns, grid co-resident; two block columns: 43.5 against 43.0 us per step); 0 (EKFVIO_SWEEP=0): one launch per block step
     size_t sweep_sync_words = 0;
+    long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
     bool sweep_flags_zeroed = false;  // gather_potrf_kernel has zeroed the flags for the sweep launch enqueued next
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
@@ -169,6 +170,7 @@ struct ekfvio_filter {
     hipGraphExec_t step_graph_big = nullptr;  // EKF_GRAPH_STEPS_BIG filter steps (long runs: fewer graph launches)
     hipGraphExec_t step_graph_pair = nullptr; // 2 filter steps (tails and short runs)
     int graph_N = -1, graph_m = -1, graph_frames = -1;
+    bool graph_sole = true;   // the graphs were captured while this was the device's only handle (persistent sweep inside)
     float graph_dt = -1.f;
     float* graph_mu = nullptr;      // orientation of the mean / covariance ping-pong at capture time
     float* graph_P = nullptr;
@@ -275,6 +277,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
                        bool first_tile_done = false, bool schur = false);
 bool sweep_supports_schur(const ekfvio_filter* f, int m_pad);
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad);
+int live_handles_on(int device);  // api.hip: handles alive on that device in this process
 // K pruned, G = K R - T[:, idx], K y partial sums (one row of f->Wt per 64 measurement columns)
 void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false, bool with_wt = true);

@@ -231,6 +231,12 @@ class TightlyCoupledEKF:
                                             _fp(Cc), M, int(variant)))
         return Cc.T.copy()
 
+    def persistent_sweeps(self):
+        """Diagnostic: sweeps of this handle that went out as the single persistent launch so far."""
+        c = C.c_int64(0)
+        self._chk(self.lib.ekfvio_test_persistent_sweeps(self.h, C.byref(c)))
+        return int(c.value)
+
     def test_cholesky_solve(self, S, Crhs):
         """Returns (L, X = Crhs @ inv(S), info)."""
         S = np.asarray(S, np.float32)

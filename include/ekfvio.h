@@ -241,6 +241,9 @@ int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int
 /* Diagnostic: s_memtime stamps of the phases of one 64x64 diagonal-block factorisation. */
 int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[80]);
 int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t stamps[1024]);
+/* Diagnostic: how many Cholesky sweeps of this handle went out as the single persistent launch (chol_persist_kernel) so far;
+   the others took one launch per block step.  Lets a test check which path it has exercised. */
+int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count);
 int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
                                float* L_out, float* X_out, int32_t* info);
 

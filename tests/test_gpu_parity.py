@@ -599,6 +599,12 @@ def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkey
                     g.process(sc.dt)
                     assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
             out[(mode, replay)] = g.get_state()
+            # (which path ran: the persistent launch from three block columns on, and never with EKFVIO_SWEEP=0)
+            blocks = (2 * (N - fails) + 63) // 64
+            if mode == "0" or blocks < 3:
+                assert g.persistent_sweeps() == 0
+            elif fails == 0:
+                assert g.persistent_sweeps() >= len(fr) - 1, (N, g.persistent_sweeps())
             g.close()
     ref = out[("0", False)]
     assert np.isfinite(ref["Sigma"]).all()
@@ -635,6 +641,36 @@ def test_persistent_per_tile_sweep_through_the_signed_factorisation(monkeypatch,
         assert rc == capi.ENUMERIC, (mode, rc)
         out[mode] = g.get_state()
         assert np.isfinite(out[mode]["Sigma"]).all()
+        assert (g.persistent_sweeps() > 0) == (mode == "2")
         g.close()
     for k in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"):
         assert np.array_equal(out["0"][k], out["2"][k]), k
+
+
+def test_persistent_sweep_is_for_a_devices_sole_handle():
+    """Two persistent launches in flight together could each hold part of the compute units and wait for workgroups the other
+    keeps out, so the single-launch sweep is used only while a handle is alone on its device; with a second handle alive
+    both take one launch per block step (same bits either way)."""
+    N = 128
+    sc = Scenario(N, seed=4)
+    fr = list(sc.frames(3))
+
+    def run(g):
+        g.addNewFeatures(sc.initial_features())
+        for z, R, p in fr:
+            g.process(sc.dt)
+            assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+        return g.get_state()
+
+    a = TightlyCoupledEKF(max_features=N)
+    alone = run(a)
+    assert a.persistent_sweeps() == len(fr)
+    a.close()
+    b = TightlyCoupledEKF(max_features=N)
+    c = TightlyCoupledEKF(max_features=N)
+    both = run(b)
+    assert b.persistent_sweeps() == 0
+    c.close()
+    b.close()
+    for k in ("base_mu", "feat_mu", "Sigma"):
+        assert np.array_equal(alone[k], both[k]), k
