@@ -572,13 +572,13 @@ def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
     assert relf(out["1"]["Sigma"], out["0"]["Sigma"]) < 2e-5 and maxabs(out["1"]["base_mu"], out["0"]["base_mu"]) < 2e-5
 
 
-@pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (100, 3), (64, 0), (40, 5), (33, 0)])
+@pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (300, 0), (300, 11), (100, 3), (64, 0), (40, 5), (33, 0)])
 def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkeypatch, N, fails):
     """The default sweep (chol_persist.inc): everything behind the first diagonal tile in ONE launch -- the chain workgroup
     keeps L_kk in LDS from step to step, every other tile has an owner workgroup that keeps it in registers for the whole
     sweep, hand-offs are write-through stores behind per-tile flags.  Same per-tile arithmetic in the same order as one
     launch per block step (EKFVIO_SWEEP=0): every bit of the state must agree, per call and in graph replay, with ragged measurement
-    counts and with one, two, four and eight block columns."""
+    counts and with one, two, four, eight and ten block columns (N = 300: 233 owner workgroups)."""
     sc = Scenario(N, seed=11)
     fr = list(sc.frames(5))
     for s, (z, R, p) in enumerate(fr):
