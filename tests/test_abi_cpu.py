@@ -157,3 +157,38 @@ def test_committed_pivot_chain_is_what_its_generator_emits():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "gen_potrf_chain.py")]).decode()
     have = open(os.path.join(ROOT, "ekf_vio_amd", "csrc", "potrf_chain.inc")).read()
     assert out == have
+
+
+def test_chain_publication_wait_counts_the_loads_behind_the_stores(tmp_path):
+    """chol_persist_kernel's chain raises ready[k] behind `s_waitcnt vmcnt(20)`: the wavefront's write-through stores of the
+    factor must be older than exactly the 20 tile loads (16 dwords of tile (i,k), 4 x 16 bytes of the diagonal tile) issued
+    in front of that wait, and nothing else may sit between them.  The count is the compiler's to keep: check the ISA."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "ekf_vio_amd", "csrc", "chol.hip")
+    out = str(tmp_path / "chol.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only",
+             "-I" + os.path.join(ROOT, "ekf_vio_amd", "csrc"), "-I" + os.path.join(ROOT, "include")]
+    subprocess.run([hipcc] + flags + [src, "-o", out], check=True, capture_output=True, timeout=600)
+    text = open(out).read()
+    m = re.search(r"^_ZN\S*chol_persist_kernel\S*:[^\n]*\n(.*?)codeLenInByte", text, re.S | re.M)
+    assert m, "kernel not found in the ISA"
+    lines = m.group(1).splitlines()
+    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(20)" in l and "ASMSTART" in lines[i - 1]]
+    assert len(waits) == 1
+    w = waits[0]
+    stores = [i for i in range(w) if re.search(r"buffer_store_dwordx4 .* sc1", lines[i])]
+    assert stores, "no write-through store in front of the wait"
+    # walk back from the wait over straight-line code: the loads of this path
+    loads = 0
+    for i in range(w - 1, -1, -1):
+        l = lines[i].strip()
+        if re.match(r"(global|buffer)_load_", l):
+            loads += 1
+        elif re.match(r"(global|buffer|flat|scratch)_(store|atomic)", l) or l.startswith(".LBB") or l.startswith("s_cbranch") or l.startswith("s_branch"):
+            break
+    assert loads == 20, loads
