@@ -674,3 +674,41 @@ def test_persistent_sweep_is_for_a_devices_sole_handle():
     b.close()
     for k in ("base_mu", "feat_mu", "Sigma"):
         assert np.array_equal(alone[k], both[k]), k
+
+
+def test_replay_graphs_follow_the_number_of_live_handles():
+    """The replay graphs contain either the persistent sweep or one launch per block step, decided when they are captured;
+    when a second handle appears on the device (or the last other one goes away) they are captured again.  Same bits
+    throughout."""
+    N = 128
+    sc = Scenario(N, seed=6)
+    fr = list(sc.frames(16))
+    zs, Rs, ps = (np.stack([f[i] for f in fr]) for i in range(3))
+
+    def fresh():
+        g = TightlyCoupledEKF(max_features=N)
+        g.addNewFeatures(sc.initial_features())
+        g.upload_measurements(zs, Rs, ps)
+        return g
+
+    ref = fresh()
+    ref.run_uploaded(0, 16, sc.dt)
+    ref.synchronize()
+    want = ref.get_state()
+    assert ref.persistent_sweeps() > 0
+    ref.close()
+
+    a = fresh()
+    a.run_uploaded(0, 8, sc.dt)  # alone: captured with the persistent sweep
+    a.synchronize()
+    alone = a.persistent_sweeps()
+    assert alone > 0
+    b = fresh()                   # a second handle on the device: a's graphs are stale
+    a.run_uploaded(8, 8, sc.dt)
+    a.synchronize()
+    assert a.persistent_sweeps() == alone, "with a second handle alive the steps must take one launch per block step"
+    got = a.get_state()
+    b.close()
+    a.close()
+    for k in ("base_mu", "feat_mu", "Sigma"):
+        assert np.array_equal(got[k], want[k]), k
