@@ -33,8 +33,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def dist_setup(n_gpus, backend=None):
-    import torch
+def dist_setup(n_gpus, backend="gloo"):
+    """The ranks exchange one barrier and one float (the max-over-ranks time): always the gloo backend on 127.0.0.1.  No
+    RCCL anywhere (BASELINE north_star: replicas, no collective on the data path) -- an RCCL barrier is a GPU kernel per
+    rank, which has no business next to a 2 ms timed region."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -45,10 +47,6 @@ def dist_setup(n_gpus, backend=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         import datetime
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     return world, rank, local
@@ -125,8 +123,7 @@ def max_over_ranks(x, world):
         return x
     import torch
     import torch.distributed as dist
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = torch.tensor([x], dtype=torch.float64)  # gloo: a host tensor
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -154,10 +151,12 @@ def selftest_dist(args):
     with a synthetic per-rank time; used by the gloo CPU tests.  Computes nothing."""
     if os.environ.get("EKFVIO_BENCH_SELFTEST_FAIL_RANK") == os.environ.get("RANK", "0"):
         raise SystemExit("selftest: rank %s dies before the rendezvous" % os.environ.get("RANK", "0"))
-    world, rank, _ = dist_setup(args.gpus, backend="gloo")
+    world, rank, _ = dist_setup(args.gpus)
     barrier(world)
-    elapsed = max_over_ranks(0.5 + 0.25 * rank, world)
+    t0 = time.perf_counter()
+    mine = 0.5 + 0.25 * rank + 0.0 * (time.perf_counter() - t0)  # (the per-rank clock of the real run, synthetic here)
     barrier(world)
+    elapsed = max_over_ranks(mine, world)
     if rank == 0:
         print(json.dumps(result_line(args, world, args.landmarks, elapsed, {"selftest": True})))
     if world > 1:
@@ -314,6 +313,55 @@ def concurrent_sequences(n_landmarks, device, sequences, steps, dt_warm=10):
             "per_sequence_steps_per_s": steps / el, "states_finite": ok}
 
 
+def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="structured", depth_var=100.0):
+    """steps/s of a device-resident run at another size or predict mode (an extra, never `value`): same procedure as the
+    headline (graphs prepared first, `steps` steps between two synchronises), median of five readings."""
+    from ekf_vio_amd import TightlyCoupledEKF, capi
+    from ekf_vio_amd.sim import Scenario
+    sc = Scenario(n_landmarks, seed=0)
+    mode = capi.PREDICT_DENSE if predict == "dense" else capi.PREDICT_STRUCTURED
+    g = TightlyCoupledEKF(max_features=n_landmarks, device=device, predict_mode=mode, default_point_depth_variance=depth_var)
+    g.addNewFeatures(sc.initial_features())
+    fr = list(sc.frames(warm + steps))
+    g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+    g.run_uploaded(0, 0, sc.dt)
+    g.run_uploaded(0, warm, sc.dt)
+    g.synchronize()
+    snap = g.get_state()
+    times, warn = [], 0
+    for _ in range(5):
+        g.set_state(snap)
+        g.run_uploaded(warm, 0, sc.dt)
+        g.synchronize()
+        t0 = time.perf_counter()
+        g.run_uploaded(warm, steps, sc.dt)
+        warn += g.synchronize() == capi.ENUMERIC
+        times.append(time.perf_counter() - t0)
+    out = {"landmarks": n_landmarks, "state_dim": 22 + 3 * n_landmarks, "steps": steps, "predict": predict,
+           "steps_per_s": steps / float(np.median(times)), "ms_per_step": 1e3 * float(np.median(times)) / steps,
+           "numeric_warnings": int(warn), "state_finite": bool(np.isfinite(g.base_mu).all()),
+           "sweep": "persistent launch" if g.sweep_counts()["persistent"] else "one launch per block step"}
+    if predict == "dense":
+        # the two dense F P F^T GEMMs (north-star form): event-bracketed device time of the gemm_predict class over 10 steps
+        g.profile(True)
+        g.run_uploaded(warm, 10, sc.dt)
+        g.synchronize()
+        rep = g.profile_report()
+        g.profile(False)
+        gp = rep.get("gemm_predict")
+        if gp and gp["launches"]:
+            n = 22 + 3 * n_landmarks
+            us = 1e3 * gp["ms"] / gp["launches"]  # one scope = the X = F P and X F^T launches, back to back
+            tf = 4.0 * n ** 3 / (us * 1e-6) / 1e12
+            out["fp_gemm_pair"] = {"flops": 4.0 * n ** 3, "pair_us_event_bracketed": us, "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                                   "note": "dense-formulation flops: F is [[A,0],[B,D]] with 358+36N non-zeros, so all but %.1f %% of these "
+                                           "multiply structural zeros (SURVEY 8(d) honesty clause); eager launches, includes host launch gaps"
+                                           % (100.0 * (358 + 36 * n_landmarks) / float(n * n))}
+    g.close()
+    return out
+
+
 def step_flops(N):
     """Algorithmic flops the step executes (dense form of the update, structured predict), DESIGN.md section 4."""
     n, m = 22 + 3 * N, 2 * N
@@ -377,14 +425,18 @@ def main():
     times, numeric = [], capi.OK
 
     def timed_region():
+        # barrier + synchronize on both sides; every rank's own clock runs over its K steps only (enqueue, device work, the
+        # handle's and the device's synchronise): the barrier in front lines the ranks up BEFORE t0, the one behind and the
+        # max-over-ranks exchange come AFTER the clock has stopped
         torch.cuda.synchronize()
         barrier(world)
         t0 = time.perf_counter()
         g.run_uploaded(args.warmup, args.steps, dt)
         rc = g.synchronize()
         torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
         barrier(world)
-        return max_over_ranks(time.perf_counter() - t0, world), rc
+        return max_over_ranks(mine, world), rc
 
     el, numeric = timed_region()
     times.append(el)
@@ -408,7 +460,8 @@ def main():
              "timed_region": {"repeats": repeats, "value_is": "median" if repeats > 1 else "single reading",
                               "steps_per_s_min": world * args.steps / max(times), "steps_per_s_max": world * args.steps / min(times),
                               "region_ms": [1e3 * t for t in times],
-                              "note": "each repetition times exactly --steps steps from the same restored state, barrier + synchronize on both sides"},
+                              "note": "each repetition times exactly --steps steps from the same restored state, barrier + synchronize on both sides; ranks meet over gloo "
+                                      "(no RCCL), each rank's clock spans its own steps only, max over ranks taken after the clocks stop"},
              "parity": "oracle unpinned against the reference binary (the reference holds one KAT, test/test_ekf.cpp:44-63; "
                        "no Eigen/ROS/OpenCV in the image to build it): HIP vs own fp32/fp64 CPU restatement, tests/ -m gpu",
              "cpu_baseline_eigen_sparse": "unavailable: no Eigen3 on this box (BASELINE.md B3)"}
@@ -433,7 +486,7 @@ def main():
                              "shape": {"M": n, "N": n, "K": m_pad}}
         # HBM-side traffic and MFMA-busy counters of the same kernels come from separate rocprofv3 --pmc passes
         # (bench.py cannot collect PMCs itself); the committed summaries are quoted when the workload matches
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_n256.json" % tag)
             if N == 256 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
@@ -443,7 +496,7 @@ def main():
                     extra["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)" % tag
                     extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
                     break
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             mf = os.path.join(ROOT, "profiles", "%s_pmc_mfma_n256.json" % tag)
             if N == 256 and os.path.exists(mf):
                 mj = json.load(open(mf))
@@ -502,6 +555,14 @@ def main():
             extra["concurrent_sequences_one_gpu"] = {"error": repr(ex)}
     if rank == 0:
         if world == 1 and not args.no_full_loop:
+            try:  # extras, never fatal: the author's deployment sizes (params/test.yaml 30, the node default 100, fast_with_insight.yaml 400
+                  # with its depth variance 1000) and the north-star dense predict beside the structured one (report both)
+                extra["other_sizes"] = [device_resident_rate(30, local, depth_var=1000.0), device_resident_rate(100, local),
+                                        device_resident_rate(400, local, depth_var=1000.0)]
+                extra["predict_dense"] = device_resident_rate(N, local, steps=100, predict="dense")
+                extra["predict_dense"]["structured_steps_per_s_same_run"] = world * args.steps / elapsed
+            except Exception as ex:
+                extra["other_sizes"] = {"error": repr(ex)}
             try:
                 extra["full_loop"] = {"n64": full_loop(64, local), "n256": full_loop(256, local),
                                       "node_defaults_n100_scale4": full_loop(100, local, node_defaults=True),

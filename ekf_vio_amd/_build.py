@@ -78,9 +78,30 @@ def _build_locked(force, verbose):
         if verbose:
             print(" ".join(cmd))
         jobs.append((cmd, subprocess.Popen(cmd)))
+    # chol.hip carries a hand-placed, COUNTED wait (chol_persist.inc: ready[k] goes up behind `s_waitcnt vmcnt(N)`): the ISA of
+    # the very compile that is being linked is checked, with the same flags, and the build fails on a mismatch
+    isa_job = None
+    if any(os.path.basename(c[-1]) == "chol.hip" for c, _ in jobs) or not os.path.exists(ISA_STAMP):
+        src = os.path.join(CSRC, "chol.hip")
+        isa = os.path.join(OBJ_DIR, "chol.device.s")
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get("chol.hip", []) + _extra_flags() + ["-S", "--cuda-device-only", "-o", isa, src]
+        if verbose:
+            print(" ".join(cmd))
+        isa_job = (cmd, subprocess.Popen(cmd), isa)
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+    if isa_job:
+        cmd, pr, isa = isa_job
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        if os.path.exists(ISA_STAMP):
+            os.remove(ISA_STAMP)
+        problems = check_counted_waits(open(isa).read())
+        if problems:
+            raise RuntimeError("chol.hip: hand-placed counted wait does not match the compiled ISA: " + "; ".join(problems))
+        with open(ISA_STAMP, "w") as fh:
+            fh.write("ok\n")
     tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
     cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
     if verbose:
@@ -91,6 +112,38 @@ def _build_locked(force, verbose):
         fh.write(_flags_key())
     os.replace(FLAGS_STAMP + ".tmp", FLAGS_STAMP)
     return LIB_PATH
+
+
+ISA_STAMP = os.path.join(OBJ_DIR, "chol.isa.checked")
+
+
+def check_counted_waits(isa_text):
+    """Every inline-asm `s_waitcnt vmcnt(N)`, N > 0, of chol_persist_kernel must have exactly N vector-memory LOADS, and
+    nothing else that vmcnt counts, in the straight-line code in front of it (vmcnt retires loads and stores in order: the
+    wait then means "everything older than these N loads -- the factor's stores -- has completed").  Returns a list of
+    problems (empty = sound)."""
+    import re
+    m = re.search(r"^_ZN\S*chol_persist_kernel\S*:[^\n]*\n(.*?)codeLenInByte", isa_text, re.S | re.M)
+    if not m:
+        return ["chol_persist_kernel not found in the ISA"]
+    lines = m.group(1).splitlines()
+    problems = []
+    waits = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\((\d+)\)", l) and i > 0 and "ASMSTART" in lines[i - 1]]
+    counted = [i for i in waits if int(re.search(r"vmcnt\((\d+)\)", lines[i]).group(1)) > 0]
+    for w in counted:
+        want = int(re.search(r"vmcnt\((\d+)\)", lines[w]).group(1))
+        # walk back over the straight-line code in front of the wait (the stores sit in front of the branch that leads here:
+        # chol_persist.inc issues them at the end of the previous step, before anything of this path)
+        loads = 0
+        for i in range(w - 1, -1, -1):
+            l = lines[i].strip()
+            if re.match(r"(global|buffer)_load_", l):
+                loads += 1
+            elif re.match(r"(global|buffer|flat|scratch)_(store|atomic)", l) or l.startswith(".LBB") or l.startswith("s_cbranch") or l.startswith("s_branch"):
+                break
+        if loads != want:
+            problems.append("vmcnt(%d) behind %d loads" % (want, loads))
+    return problems
 
 
 HOST_DIR = os.path.join(_HERE, "host")

@@ -372,13 +372,45 @@ int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense) {
     return EKFVIO_OK;
 }
 
-static int finish_update(ekfvio_filter* f) {
+}  // extern "C"
+
+// The status word f->info[0]: bit 0 = a non-positive pivot was met (a warning: the reference logs and carries on,
+// TightlyCoupledEKF.cpp:577-580), bit 1 = the persistent sweep ran out of patience (its workgroups were not all
+// resident: another process or stream held compute units).  Behind an aborted sweep the Joseph GEMMs write nothing, so
+// Sigma, mu and the frame counter stand where process(dt) left them, and the handle stops using the persistent launch.
+void sweep_abort_latch(ekfvio_filter* f) {
+    f->sweep_mode = 0;  // every later sweep of this handle: one launch per block step (no co-residency needed)
+    drop_graph(f);      // captured steps contain the persistent launch
+}
+// Waits for the stream and reads the status word.  An aborted update is enqueued again by `rerun` (null: the caller cannot,
+// e.g. a graph replay of many steps: EKFVIO_EABORTED) with the per-step sweep and awaited: fresh launches, same inputs,
+// and the state comes out as if the per-step sweep had run in the first place.
+int finish_update_rerun(ekfvio_filter* f, void (*rerun)(ekfvio_filter*, void*), void* ctx) {
     int bad = 0;
-    const int rc = wait_status(f, &bad);
+    int rc = wait_status(f, &bad);
     if (rc != EKFVIO_OK) return rc;
     if (bad) HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
-    return bad ? EKFVIO_ENUMERIC : EKFVIO_OK;
+    if (bad & 2) {
+        sweep_abort_latch(f);
+        if (!rerun) {
+            f->last_error = "persistent sweep aborted (compute units shared with other work): updates behind it were skipped, the state is "
+                            "the propagated one; this handle now takes one launch per block step";
+            return EKFVIO_EABORTED;
+        }
+        f->sweep_recoveries++;
+        rerun(f, ctx);
+        HIPC(f, hipGetLastError());
+        rc = wait_status(f, &bad);
+        if (rc != EKFVIO_OK) return rc;
+        if (bad) HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
+        if (bad & 2) return EKFVIO_EABORTED;  // (cannot happen: the per-step sweep has no waits)
+    }
+    return (bad & 1) ? EKFVIO_ENUMERIC : EKFVIO_OK;
 }
+
+extern "C" {
+
+static int finish_update(ekfvio_filter* f) { return finish_update_rerun(f, nullptr, nullptr); }
 
 int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count) {
     if (!f || count != f->N) return EKFVIO_EINVAL;  // ROS_ASSERT :478
@@ -400,7 +432,11 @@ int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_
     }
     launch_update(f, m, dz, dR, dp);
     HIPC(f, hipGetLastError());
-    return finish_update(f);
+    struct Ctx { int m; float *dz, *dR; uint8_t* dp; } ctx{m, dz, dR, dp};
+    return finish_update_rerun(f, [](ekfvio_filter* g, void* c) {
+        const Ctx* x = static_cast<const Ctx*>(c);
+        launch_update(g, x->m, x->dz, x->dR, x->dp);  // the staged measurement is still in d_meas; the bookkeeping is idempotent
+    }, &ctx);
 }
 
 int ekfvio_measurement_map(const ekfvio_filter* f, const uint8_t* measured, int32_t count, int32_t* idx, int32_t* rows) {
@@ -923,6 +959,23 @@ int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t* stamps /* [1
 int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count) {
     if (!f || !count) return EKFVIO_EINVAL;
     *count = f->persistent_sweeps;
+    return EKFVIO_OK;
+}
+
+int ekfvio_test_sweep_counts(ekfvio_filter* f, int64_t counts[4]) {
+    if (!f || !counts) return EKFVIO_EINVAL;
+    counts[0] = f->persistent_sweeps;
+    counts[1] = f->schur_sweeps;
+    counts[2] = f->sweep_recoveries;
+    counts[3] = f->sweep_mode;
+    return EKFVIO_OK;
+}
+
+int ekfvio_test_sweep_fault(ekfvio_filter* f, int32_t spin_limit, int32_t stall_workgroup) {
+    if (!f || spin_limit < 0) return EKFVIO_EINVAL;
+    f->sweep_spin_limit = spin_limit;
+    f->sweep_stall_wg = stall_workgroup;
+    drop_graph(f);  // captured launches carry the old arguments
     return EKFVIO_OK;
 }
 

@@ -1349,7 +1349,7 @@ bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     const int rows = 2 * mb + n_pad / PB;
     // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
-    return f->sweep_mode == 2 && live_handles_on(f->device) <= 1 && mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
+    return f->sweep_mode == 2 && !sweep_supports_schur(f, m_pad) && live_handles_on(f->device) <= 1 && mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
            persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
 }
 
@@ -1362,6 +1362,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int idb0 = mb + n_pad / PB;
     const bool flags_zeroed = f->sweep_flags_zeroed;  // (by gather_potrf_kernel, the launch in front, in the filter's update)
     f->sweep_flags_zeroed = false;
+    f->sweep_abort_word = nullptr;
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     if (!schur && sweep_is_persistent(f, m_pad, n_pad)) {
@@ -1374,6 +1375,9 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.fin = f->sweep_sync + mb;
         pa.abort_flag = f->sweep_sync + mb + (mb + rb) * mb;
         pa.dbg = f->sweep_dbg;
+        pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+        pa.stall_wg = f->sweep_stall_wg;
+        f->sweep_abort_word = pa.abort_flag;  // the kernels behind this sweep leave the state alone if it is raised (launch_update)
         if (!flags_zeroed) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
         hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
         f->persistent_sweeps++;
@@ -1383,6 +1387,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const bool split = mb >= EKF_SWEEP_SPLIT_MB;
     SchurArgs sc;
     if (schur && !split) {
+        f->schur_sweeps++;
         // T and K as Schur tiles of the sweep itself (chol_step_kernel): Sigma is updated in place, the gain lands in Km
         sc.P = f->P;
         sc.ldp = f->ldp;
@@ -1504,7 +1509,8 @@ void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_de
 // K <- K + (Y - K L) L^-1 (two more GEMMs); on the filter's matrices it changes nothing
 // measurable (the error is dominated by the fp32 factor itself), so it is off by default.
 bool sweep_supports_schur(const ekfvio_filter* f, int m_pad) {
-    return f->schur && f->sweep_mode == 0 && m_pad / PB < EKF_SWEEP_SPLIT_MB;
+    // (EKFVIO_SCHUR=1 takes precedence over the persistent launch: launch_chol_sweep skips that path when `schur` is set)
+    return f->schur && m_pad / PB < EKF_SWEEP_SPLIT_MB;
 }
 
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,

@@ -103,6 +103,11 @@ struct ekfvio_filter {
                                // applies (3 .. 15 block columns, grid co-resident; two block columns: 43.5 against 43.0 us per step); 0 (EKFVIO_SWEEP=0): one launch per block step
     size_t sweep_sync_words = 0;
     long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
+    long long schur_sweeps = 0;       // sweeps enqueued with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1): ekfvio_test_sweep_counts
+    long long sweep_recoveries = 0;   // updates run again with the per-step sweep behind an aborted persistent launch
+    int sweep_spin_limit = 0;         // > 0: looks per wait of the persistent sweep (test hook ekfvio_test_sweep_fault); 0: SWEEP_SPIN_LIMIT
+    int sweep_stall_wg = -1;          // fault injection: this workgroup of the persistent launch never raises its flag
+    const int* sweep_abort_word = nullptr;  // abort word of the persistent sweep enqueued last by launch_chol_sweep (null: another sweep)
     bool sweep_flags_zeroed = false;  // gather_potrf_kernel has zeroed the flags for the sweep launch enqueued next
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
@@ -210,6 +215,8 @@ struct GemmEpi {
     int* frame_counter = nullptr;
     int frames = 0;
     long long* stamps = nullptr;  // diagnostic s_memtime stamps (library built with -DEKF_GEMM_STAMPS), per handle
+    const int* abort = nullptr;   // modes 1-3: abort word of the persistent sweep in front (non-zero: the factor is unfinished) --
+                                  // the kernel then writes nothing: Sigma, mu and the frame counter stay as process(dt) left them
 };
 void launch_gemm(ekfvio_filter* f, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                  int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB = 0,
@@ -261,6 +268,9 @@ int fast_ensure(ekfvio_filter* f, int w, int h);  // grows the detector's per-pi
 int wait_status(ekfvio_filter* f, int* status, const int* extra_dev = nullptr, int* extra_out = nullptr);
 // the same in two halves, for a caller whose own (single-workgroup) kernel publishes the words itself
 int next_status_seq(ekfvio_filter* f);
+// api.hip: what a host does when the status word says the persistent sweep gave up (bit 1): the handle goes to the per-step
+// sweep for good and its captured graphs are dropped
+void sweep_abort_latch(ekfvio_filter* f);
 int poll_status(ekfvio_filter* f, int seq, int* status, int* extra_out);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
 int add_features_device(ekfvio_filter* f, int k);

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         if (dbg && tid == 0) {                                                                                      \
             const int b_ = (int)blockIdx.x;                                                                         \
             const int w_ = b_ == 0 ? 0 : b_ == 1 ? 1 : b_ == ntile ? 2 : b_ == ntile + 1 ? 3 : b_ == ntile + chunks + 1 ? 4 : -1; \
-            if (w_ >= 0) dbg[700 + 8 * w_ + (slot)] = (long long)__builtin_amdgcn_s_memtime();                      \
+            if (w_ >= 0) dbg[900 + 8 * w_ + (slot)] = (long long)__builtin_amdgcn_s_memtime();                      \
         }                                                                                                           \
     } while (0)
     PSTAMP_(0);
@@ -986,6 +986,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather, true);
         launch_joseph_g(f, m, m_pad, n_pad, m_on_device);
         ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad, 1);
+        e2.abort = nullptr;
         e2.mode = 3;  // the mean takes K y from joseph_g_kernel's partial sums
         e2.Kyp = f->Wt;
         e2.kyp_blocks = m_pad / 64;
@@ -1006,6 +1007,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             e1.Rm = f->Rm;
             e1.G = f->Gm;
             e1.ldg = ld;
+            e1.abort = e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: both GEMMs write nothing
             launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
             launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
         }

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     const int li = lane & 31;
     const int lk = lane >> 5;
+    // an aborted persistent sweep in front (chol_persist.inc): requested here, looked at in front of the epilogue's writes
+    int sweep_aborted = 0;
+    if (EPI != 0 && epi.abort) sweep_aborted = *epi.abort;
 
     // Software pipeline, one barrier per 32-deep K-tile.  In iteration t, between the 16
     // dependent MFMAs of tile t (each holds the wave's issue for 64 cycles) the wave also
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
 #undef GEMM_TILE
 
     GSTAMP(37);
+    if (EPI != 0 && sweep_aborted) return;  // (uniform over the grid) the state stays as process(dt) left it
     // epilogue: lane -> row i (contiguous), register -> column j.  All 16 outputs are formed
     // first; interior tiles then store without per-element tests.
     const int i = i0 + wr * 32 + li;
@@ -437,6 +441,9 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     f32x4 acc[RB];
 #pragma unroll
     for (int a = 0; a < RB; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // an aborted persistent sweep in front (chol_persist.inc): requested here, looked at in front of the epilogue's writes
+    int sweep_aborted = 0;
+    if (EPI != 0 && epi.abort) sweep_aborted = *epi.abort;
 
     // the C tile this wave will update is requested first (see the 32x32 kernel)
     float cpre[RB][4];
@@ -647,6 +654,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     }
 
     GSTAMP(37);
+    if (EPI != 0 && sweep_aborted) return;  // (uniform over the grid) the state stays as process(dt) left it
     // epilogue: lane -> row (contiguous in memory), register -> column
     float vout[RB][4];
 #pragma unroll

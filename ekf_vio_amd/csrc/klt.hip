@@ -1352,15 +1352,30 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         rc = poll_status(f, seq, &bad, &added);
     }
     if (rc != EKFVIO_OK) return rc;
+    f->out_fresh = f->frame_outputs != 0;
+    if (bad) HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
+    if (bad & 2) {
+        // The persistent sweep gave up (chol_persist.inc): the Joseph GEMMs wrote nothing, the state is the propagated one.
+        // The update runs again now, with one launch per block step, over the landmarks it was enqueued for (the count is
+        // bumped below): idx, the measured coordinates per row, R and the row count are where the bookkeeping left them;
+        // rows and columns of landmarks the replenishment has added meanwhile lie outside n and are not touched.  (Those
+        // landmarks were picked around the predicted, not the updated, landmark pixels: a valid state, not bit for bit the
+        // frame an unshared GPU produces.)
+        sweep_abort_latch(f);
+        f->sweep_recoveries++;
+        f->out_fresh = false;
+        launch_update(f, 0, f->zmeas, f->Rmeas, f->pass, nullptr, 0, true, true);
+        HIPK(f, hipGetLastError());
+        rc = wait_status(f, &bad);
+        if (rc != EKFVIO_OK) return rc;
+        if (bad) HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
+        if (bad & 2) return EKFVIO_EABORTED;
+    }
     if (added > 0) {
         f->N += added;
         f->n += 3 * added;
     }
-    f->out_fresh = f->frame_outputs != 0;
-    if (bad) {
-        status = EKFVIO_ENUMERIC;
-        HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
-    }
+    if (bad & 1) status = EKFVIO_ENUMERIC;
     return status;
 }
 

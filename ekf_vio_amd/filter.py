@@ -237,6 +237,16 @@ class TightlyCoupledEKF:
         self._chk(self.lib.ekfvio_test_persistent_sweeps(self.h, C.byref(c)))
         return int(c.value)
 
+    def sweep_counts(self):
+        """Diagnostic: dict(persistent, schur, recoveries, mode) of this handle's Cholesky sweeps (ekfvio_test_sweep_counts)."""
+        c = (C.c_int64 * 4)()
+        self._chk(self.lib.ekfvio_test_sweep_counts(self.h, c))
+        return dict(persistent=int(c[0]), schur=int(c[1]), recoveries=int(c[2]), mode=int(c[3]))
+
+    def sweep_fault(self, spin_limit=0, stall_workgroup=-1):
+        """Fault injection for the persistent sweep (ekfvio_test_sweep_fault)."""
+        self._chk(self.lib.ekfvio_test_sweep_fault(self.h, int(spin_limit), int(stall_workgroup)))
+
     def test_cholesky_solve(self, S, Crhs):
         """Returns (L, X = Crhs @ inv(S), info)."""
         S = np.asarray(S, np.float32)
@@ -337,11 +347,14 @@ class EKFVIO:
         h, w = img.shape
         K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
         self._drain_imu(float(stamp))  # IMU records up to this frame's stamp, in stamp order, before the frame itself
-        rc = self.tc_ekf._chk(self.tc_ekf.lib.ekfvio_step_image(self.tc_ekf.h, float(stamp), _u8(img), w, h, w, _fp(K)),
-                              allow=(capi.ENUMERIC,))
-        self._t_filter = float(stamp) if self._t_filter is None else max(self._t_filter, float(stamp))
-        self._last_K = K.copy()
-        return rc
+        rc = self.tc_ekf.lib.ekfvio_step_image(self.tc_ekf.h, float(stamp), _u8(img), w, h, w, _fp(K))
+        # ekfvio_step_image moves the device clock as soon as process(dt) is enqueued; only EINVAL / ECAPACITY refuse the frame
+        # before that.  The host's queue clock follows whenever the predict went out, whatever happened behind it, so that a
+        # failed frame does not leave IMU records between the two stamps queued for a filter that is already past them.
+        if rc not in (capi.EINVAL, capi.ECAPACITY):
+            self._t_filter = float(stamp) if self._t_filter is None else max(self._t_filter, float(stamp))
+            self._last_K = K.copy()
+        return self.tc_ekf._chk(rc, allow=(capi.ENUMERIC,))
 
     def replenishFeatures(self):
         """EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame, on the device: FAST-9/16 with
@@ -403,6 +416,8 @@ class EKFVIO:
     def insight(self):
         """publishInsight's image (EKFVIO.cpp:379-442): the resized frame as BGR8 [h, w, 3] with a green 22-pixel square
         (cv::drawMarker MARKER_SQUARE) at the pixel of every landmark that is not flagged for deletion."""
+        if self._last_K is None:
+            raise capi.EkfvioError(capi.ESTATE, "insight() before the first frame")
         grey, _ = self.tracker.level(0)
         h, w = grey.shape
         out = np.repeat(grey[:, :, None], 3, axis=2).copy()

@@ -360,7 +360,9 @@ class EKFVIO {
     bool addFrame(const Frame& f) {
         drainImu(f.t);  // IMU records up to this frame's stamp, in stamp order, before the frame itself
         int rc = ekfvio_step_image(tc_ekf.handle(), f.t, f.img, f.cols, f.rows, f.step, f.K.data());
-        if (rc == EKFVIO_OK || rc == EKFVIO_ENUMERIC) {
+        // ekfvio_step_image moves the device clock as soon as process(dt) is enqueued; only EINVAL / ECAPACITY refuse the frame
+        // before that.  The queue clock follows whenever the predict went out, whatever happened behind it.
+        if (rc != EKFVIO_EINVAL && rc != EKFVIO_ECAPACITY) {
             last_stamp_ = f.t;
             if (!have_time_ || f.t > t_filter_) t_filter_ = f.t;
             have_time_ = true;
@@ -388,6 +390,7 @@ class EKFVIO {
     }
     // what publishInsight(cf) sends (EKFVIO.cpp:379-442); needs a frame
     Insight insight() {
+        if (!have_time_) throw Error(EKFVIO_ESTATE, "insight() before the first frame");
         Insight o;
         o.stamp = last_stamp_;
         int32_t w = 0, h = 0;

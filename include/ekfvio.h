@@ -9,7 +9,10 @@
  * caller owns every host buffer; all device state (mean, dense covariance, image
  * pyramids, work buffers) is owned by the opaque handle.  One handle = one HIP stream on
  * one device; calls on one handle must be serialised by the caller; different handles are
- * fully independent (no globals, no statics).
+ * independent: no handle reads another's state.  The library's only process-wide state is a per-device count of live
+ * handles (a device's SOLE handle may run the Cholesky sweep as one persistent launch, which needs every compute unit it
+ * asks for; with several handles on a device each takes one launch per block step: same results) and the values of
+ * diagnostic environment switches (EKFVIO_*), read once.
  *
  * Layouts: vectors of 2-D points are x,y interleaved f32 (std::vector<Eigen::Vector2f>);
  * 2x2 covariances are column-major f32 (std::vector<Eigen::Matrix2f>); flags are one byte
@@ -37,7 +40,13 @@ enum {
                             TightlyCoupledEKF.cpp:579, then continues); state is still updated */
     EKFVIO_ECAPACITY = 3,/* more landmarks than config.max_features */
     EKFVIO_EDEVICE = 4,  /* HIP runtime failure; ekfvio_last_error() has the text */
-    EKFVIO_ESTATE = 5    /* call sequence error (e.g. KLT track before two frames exist) */
+    EKFVIO_ESTATE = 5,   /* call sequence error (e.g. KLT track before two frames exist) */
+    EKFVIO_EABORTED = 6  /* the persistent Cholesky sweep could not get its workgroups resident together (another process or
+                            stream held compute units) and gave up.  NOT a numeric warning: the updates behind it were
+                            skipped -- Sigma, mu are the propagated ones, never a half-finished factor's.  ekfvio_update and
+                            ekfvio_step_image do not return it: they run the update again at once with one launch per block
+                            step.  ekfvio_synchronize returns it for a device-resident run (ekfvio_run_uploaded), whose skipped
+                            updates cannot be replayed.  Either way the handle uses the per-step sweep from then on. */
 };
 
 enum { EKFVIO_PREDICT_STRUCTURED = 0, /* exploits F = [[A,0],[B,D]] (nnz = 358+36N) */
@@ -104,7 +113,8 @@ int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense);
 
 /* updateWithFeaturePositions(z, R, pass) (TightlyCoupledEKF.cpp:475-628).  `count` must
  * equal the number of landmarks (reference ROS_ASSERT at :478).  Entries of z/R for
- * failed landmarks are ignored.  Returns EKFVIO_OK or EKFVIO_ENUMERIC. */
+ * failed landmarks are ignored.  Returns EKFVIO_OK or EKFVIO_ENUMERIC (an aborted persistent sweep is
+ * recovered inside the call, see EKFVIO_EABORTED). */
 int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count);
 
 /* formFeatureMeasurementMap (TightlyCoupledEKF.cpp:634-661): state index of the single 1.0
@@ -214,7 +224,8 @@ int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z,
  * capture costs milliseconds: a caller that times a run prepares first). */
 int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt);
 /* Waits for the handle's stream.  Returns EKFVIO_ENUMERIC (once) if a run since the last status read met a
- * non-positive pivot (reference: ROS_ERROR_COND at TightlyCoupledEKF.cpp:579, continues), else EKFVIO_OK. */
+ * non-positive pivot (reference: ROS_ERROR_COND at TightlyCoupledEKF.cpp:579, continues); EKFVIO_EABORTED if a persistent
+ * sweep of the run gave up (the updates behind it were skipped; see the enum); else EKFVIO_OK. */
 int ekfvio_synchronize(ekfvio_filter* f);
 
 /* ---- instrumentation ----------------------------------------------------------------- */
@@ -244,6 +255,12 @@ int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t stamps[1024])
 /* Diagnostic: how many Cholesky sweeps of this handle went out as the single persistent launch (chol_persist_kernel) so far;
    the others took one launch per block step.  Lets a test check which path it has exercised. */
 int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count);
+/* Diagnostic: counts[0] persistent sweeps, [1] sweeps with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1), [2] updates run
+   again behind an aborted persistent sweep, [3] the handle's sweep mode now (2: persistent where it applies, 0: per-step). */
+int ekfvio_test_sweep_counts(ekfvio_filter* f, int64_t counts[4]);
+/* Fault injection for the persistent sweep: at most `spin_limit` looks per wait (0: the production limit), and workgroup
+   `stall_workgroup` of the launch never raises its tile's flag (-1: none), so every wait behind it runs out. */
+int ekfvio_test_sweep_fault(ekfvio_filter* f, int32_t spin_limit, int32_t stall_workgroup);
 int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
                                float* L_out, float* X_out, int32_t* info);
 

@@ -16,7 +16,7 @@ g.lib.ekfvio_test_sweep_stamps(g.h, 1, st)
 v = list(st)
 names = ["diagonal tile (0,0)", "tile (0,1)", "base workgroup 0 (22x22)", "base rows, chunk 0", "base columns, chunk 0"]
 for w in range(5):
-    b = 700 + 8 * w
+    b = 900 + 8 * w
     s = [v[b + i] for i in range(5)]
     if w < 2:
         print("%-26s loads + base motions %5d  derivative columns %5d  X on base columns %5d  3x3 blocks (P loads, products, stores) %5d  | total %5d cycles" % (

@@ -9,8 +9,8 @@ from oracle import KltFrame, OracleFilter, frame_resize, klt_track, replenish
 
 class OracleNode:
     def __init__(self, max_features, K, inverse_image_scale=1, dtype=np.float32, fast_threshold=50, min_new_feature_dist=30,
-                 kill_pad=11, win=21, max_level=3, do_replenish=True):
-        self.ekf = OracleFilter(dtype)
+                 kill_pad=11, win=21, max_level=3, do_replenish=True, depth_var=100.0):
+        self.ekf = OracleFilter(dtype, depth_var=depth_var)
         self.max_features = int(max_features)
         self.scale = int(inverse_image_scale)
         K = np.asarray(K, np.float32).reshape(9).copy()

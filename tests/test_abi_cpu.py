@@ -159,36 +159,18 @@ def test_committed_pivot_chain_is_what_its_generator_emits():
     assert out == have
 
 
-def test_chain_publication_wait_counts_the_loads_behind_the_stores(tmp_path):
-    """chol_persist_kernel's chain raises ready[k] behind `s_waitcnt vmcnt(20)`: the wavefront's write-through stores of the
-    factor must be older than exactly the 20 tile loads (16 dwords of tile (i,k), 4 x 16 bytes of the diagonal tile) issued
-    in front of that wait, and nothing else may sit between them.  The count is the compiler's to keep: check the ISA."""
-    import re
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
-    src = os.path.join(ROOT, "ekf_vio_amd", "csrc", "chol.hip")
-    out = str(tmp_path / "chol.s")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only",
-             "-I" + os.path.join(ROOT, "ekf_vio_amd", "csrc"), "-I" + os.path.join(ROOT, "include")]
-    subprocess.run([hipcc] + flags + [src, "-o", out], check=True, capture_output=True, timeout=600)
-    text = open(out).read()
-    m = re.search(r"^_ZN\S*chol_persist_kernel\S*:[^\n]*\n(.*?)codeLenInByte", text, re.S | re.M)
-    assert m, "kernel not found in the ISA"
-    lines = m.group(1).splitlines()
-    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(20)" in l and "ASMSTART" in lines[i - 1]]
-    assert len(waits) == 1
-    w = waits[0]
-    stores = [i for i in range(w) if re.search(r"buffer_store_dwordx4 .* sc1", lines[i])]
-    assert stores, "no write-through store in front of the wait"
-    # walk back from the wait over straight-line code: the loads of this path
-    loads = 0
-    for i in range(w - 1, -1, -1):
-        l = lines[i].strip()
-        if re.match(r"(global|buffer)_load_", l):
-            loads += 1
-        elif re.match(r"(global|buffer|flat|scratch)_(store|atomic)", l) or l.startswith(".LBB") or l.startswith("s_cbranch") or l.startswith("s_branch"):
-            break
-    assert loads == 20, loads
+def test_chain_publication_wait_counts_the_loads_behind_the_stores():
+    """chol_persist_kernel's chain raises ready[k] behind a COUNTED `s_waitcnt vmcnt(N)`: the wavefront's write-through stores
+    of the factor must be older than exactly the N tile loads issued in front of that wait, and nothing else may sit between
+    them.  The count is the compiler's to keep, so ekf_vio_amd/_build.py checks the ISA of the very compile it links (same
+    flags) and refuses to build on a mismatch; here: the checker itself on good and bad ISA, and the stamp of the shipped
+    build."""
+    from ekf_vio_amd import _build
+    good = "_ZN1x19chol_persist_kernelE:\n buffer_store_dwordx4 v[0:3], v4, s[0:3], 0 offen sc1\n" + " buffer_load_dword v1, v2, s[0:3], 0 offen\n" * 3 + \
+           " ;;#ASMSTART\n s_waitcnt vmcnt(3)\n ;;#ASMEND\n codeLenInByte = 4\n"
+    assert _build.check_counted_waits(good) == []
+    assert _build.check_counted_waits(good.replace("vmcnt(3)", "vmcnt(2)")) != []
+    assert _build.check_counted_waits(good.replace("sc1\n", "sc1\n buffer_load_dword v9, v2, s[0:3], 0 offen\n", 1)) != []
+    assert _build.check_counted_waits("nothing here") != []
+    _build.build()
+    assert os.path.exists(_build.ISA_STAMP), "the shipped library was linked without the ISA check"

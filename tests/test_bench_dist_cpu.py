@@ -68,3 +68,26 @@ def test_a_rank_that_dies_before_the_rendezvous_ends_the_run_with_its_stderr():
     assert out.returncode != 0 and time.time() - t0 < 120
     assert "rank 1 exited" in out.stderr and "dies before the rendezvous" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_eight_rank_rehearsal_over_gloo_under_the_drivers_launcher():
+    """the driver's N = 8 launch line (torch.distributed.run, one rank per GPU) rehearsed on the CPU with
+    the plumbing only.  The ranks meet over gloo -- bench.py never creates an RCCL group (BASELINE north_star: no RCCL) -- each
+    rank's clock spans its own steps, and the max over ranks (rank 7: 0.5 + 7 * 0.25 s) is taken after the clocks stop."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "200",
+           "--warmup", "10", "--selftest-dist"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["sequences"] == 8 and r["scaling"] == "weak"
+    assert abs(r["value"] - 8 * 200 / 2.25) < 1e-6
+
+
+def test_bench_never_asks_for_an_rccl_process_group():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"nccl"' not in src and "'nccl'" not in src
+    assert 'backend="gloo"' in src

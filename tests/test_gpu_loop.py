@@ -185,15 +185,18 @@ def test_teacher_forced_image_loop_with_replenishment():
     v.tc_ekf.close()
 
 
-def test_free_running_loop_loses_what_the_oracle_loop_loses():
-    """46 frames of a 1.4 px / frame translation at N = 256.  Both loops run free (no teacher
-    forcing); their rounding differs, so states are compared loosely -- what must agree is the behaviour: how many
-    landmarks are ever lost, how many frames raise the numeric warning, and that both track the image motion."""
+@pytest.mark.parametrize("thr,dist,expect_n", [(50, 30, 90), (20, 12, 250)])
+def test_free_running_loop_loses_what_the_oracle_loop_loses(thr, dist, expect_n):
+    """46 frames of a 1.4 px / frame translation, capacity 256.  With the node's default
+    detector (FAST 50, 30 px) the 640x480 image yields ~105 landmarks; with FAST 20 / 12 px -- the settings of bench.py's
+    `full_loop.n256` -- the filter really runs 256.  Both loops run free (no teacher forcing); their rounding differs, so
+    states are compared loosely -- what must agree is the behaviour: how many landmarks are ever lost, how many frames raise
+    the numeric warning, and that both track the image motion."""
     base = grey()
     frames = 46
     seq = translated_sequence(base, frames)
-    v = EKFVIO(max_features=256, replenish=1)
-    node = OracleNode(256, K)
+    v = EKFVIO(max_features=256, replenish=1, fast_threshold=thr, min_new_feature_dist=dist)
+    node = OracleNode(256, K, fast_threshold=thr, min_new_feature_dist=dist)
     warn_g = warn_o = 0
     for i, img in enumerate(seq):
         stamp = 1.0 + i / 30.0
@@ -206,8 +209,13 @@ def test_free_running_loop_loses_what_the_oracle_loop_loses():
     sg, so = v.tc_ekf.get_state(), node.ekf.get_state()
     lost_g, lost_o = int(sg["del_flag"].sum()), int(so["del_flag"].sum())
     n_g, n_o = v.tc_ekf.num_features, node.ekf.num_features
-    print("free-running 46 frames: HIP lost %d of %d (warnings %d), oracle loop lost %d of %d (warnings %d)" % (
-        lost_g, n_g, warn_g, lost_o, n_o, warn_o))
+    line = "free-running 46 frames, FAST %d / %d px: HIP lost %d of %d (warnings %d), oracle loop lost %d of %d (warnings %d)" % (
+        thr, dist, lost_g, n_g, warn_g, lost_o, n_o, warn_o)
+    print(line)
+    os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "free_running_loop.txt"), "a") as fh:
+        fh.write(line + "\n")
+    assert n_o >= expect_n and n_g >= expect_n, (n_g, n_o)  # the case really runs the landmark count it is named for
     assert np.isfinite(sg["base_mu"]).all() and np.isfinite(sg["Sigma"]).all()
     # the HIP loop may not be worse than the reference arithmetic by more than a few landmarks / frames
     assert lost_g <= lost_o + max(4, lost_o // 4), (lost_g, lost_o)

@@ -560,7 +560,13 @@ def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
             o64.set_state(g.get_state())
         assert g.updateWithFeaturePositions(z, R, p) == capi.OK
         out[mode] = g.get_state()
+        # which path ran (with the persistent launch the default, EKFVIO_SCHUR=1 alone must still select the Schur sweep)
+        c = g.sweep_counts()
+        assert c["schur"] == (1 if mode == "1" else 0), (mode, c)
+        if mode == "1":
+            assert c["persistent"] == 0, c
         g.close()
+    assert not np.array_equal(out["1"]["Sigma"], out["0"]["Sigma"])  # two summation orders, not one path compared with itself
     o32 = OracleFilter(np.float32)
     o32.set_state(o64.get_state())
     o32.update(z, R, p), o64.update(z, R, p)

@@ -105,6 +105,8 @@ def test_teacher_forced_n256_including_failed_landmarks(oracle_threads, monkeypa
         teacher.process(sc.dt), teacher.update(z, R, p)
     # the two fp32 evaluations differ in rounding order only
     assert worst["sig_pair"] < 1e-4, worst
+    c = g.sweep_counts()  # which sweep the four updates took: the Schur tiles with EKFVIO_SCHUR=1, else the persistent launch
+    assert (c["schur"], c["persistent"]) == ((4, 0) if schur == "1" else (0, 4)), c
     g.close()
 
 
