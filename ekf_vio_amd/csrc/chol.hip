@@ -1514,12 +1514,12 @@ bool sweep_supports_schur(const ekfvio_filter* f, int m_pad) {
 }
 
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
-                            float* scratch, int ldk, int refine) {
+                            float* scratch, int ldk, int refine, const GemmEpi* epi) {
     ProfScope ps(f, PC_SOLVE, (refine ? 3.0 : 1.0) * n * (double)m_pad * m_pad);
     const float* Lf = Laug;
     const float* Y = Laug + m_pad;
     const float* LinvT = Laug + m_pad + n_pad;
-    launch_gemm(f, 1, n, m_pad, m_pad, 1.f, Y, ld, LinvT, ld, 0.f, nullptr, 0, K, ldk, refine ? 0 : 1, 1);
+    launch_gemm(f, 1, n, m_pad, m_pad, 1.f, Y, ld, LinvT, ld, 0.f, nullptr, 0, K, ldk, refine ? 0 : 1, 1, refine ? nullptr : epi);
     if (refine) {
         launch_gemm(f, 0, n, m_pad, m_pad, -1.f, K, ldk, Lf, ld, 1.f, Y, ld, scratch, ldk, 0, 1);     // Y - K L
         launch_gemm(f, 1, n, m_pad, m_pad, 1.f, scratch, ldk, LinvT, ld, 1.f, K, ldk, K, ldk, 1, 1);  // + prune
