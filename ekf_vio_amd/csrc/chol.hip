@@ -1315,9 +1315,15 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps, (w && atoi(w)) ? 2 : 1);
 }
 
-static size_t persist_flag_words(int m_pad, int n_pad) {  // ready[mb] + fin[row blocks x mb] + abort word, a multiple of 16 bytes
+// ready[mb] + fin[row blocks x mb] + the gather counter + the abort word (last: whoever zeroes the flags for the next sweep leaves it
+// alone, persist_zero_words), a multiple of 16 bytes
+static size_t persist_flag_words(int m_pad, int n_pad) {
     const int mb = m_pad / PB, rows = 2 * mb + n_pad / PB;
-    return ((size_t)(mb + rows * mb + 1) + 3) & ~(size_t)3;
+    return ((size_t)(mb + rows * mb + 2) + 3) & ~(size_t)3;
+}
+int persist_zero_words(int m_pad, int n_pad) {
+    const int mb = m_pad / PB, rows = 2 * mb + n_pad / PB;
+    return mb + rows * mb + 1;
 }
 #define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, bool with_wt) {
@@ -1331,7 +1337,7 @@ void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_o
     if (sweep_is_persistent(f, m_pad, n_pad)) {
         ga.zero_words = f->sweep_sync;
         ga.n_zero = (int)persist_flag_words(m_pad, n_pad);
-        f->sweep_flags_zeroed = true;  // (launch_chol_sweep, called next, skips its memset)
+        f->sweep_flags_clean = true;  // (launch_chol_sweep, called next, skips its memset)
     }
     const int nb2 = with_wt ? (m_pad / 64) * (f->ldp / 64) : 0;  // 64x64 transposing tiles of Wt (only the first Joseph GEMM reads it)
     hipLaunchKernelGGL(gather_potrf_kernel, dim3(1 + ga.nb1 + nb2), dim3(256), EKF_GATHER_POTRF_LDS, f->stream, ga, f->Laug, f->ld_aug,
@@ -1353,6 +1359,46 @@ bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
            persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
 }
 
+// The update's whole front in ONE launch (round 4): the measurement gather, the first diagonal tile and the sweep behind it.
+// Nobody writes the whole augmented matrix [A; X; I] any more: workgroup 0 gathers tile (0,0) straight from Sigma, factors it, keeps
+// it in LDS and goes on as the chain; every owner gathers ITS tile and the two block-column-0 panel sources of its first step itself
+// (chol_persist.inc, GTile); two workgroups gather the chain's first two tiles, (1,0) and (1,1), and hand them over like finished
+// tiles; workgroups 1 .. G transpose (H Sigma)^T into Wt for the first Joseph GEMM and wait for nothing.  Against gather_potrf_kernel + chol_persist_kernel: no kernel boundary on the chain, no store and cold reload of
+// L_00, no 5.5 MB of Saug written and read back.  A few more workgroups than compute units at N = 256 (260): the transposing ones
+// come first and never wait, the last owners get their compute unit microseconds later and are needed last.  The launch asks for
+// > 80 KB of LDS so that every workgroup has a compute unit of its own (the pivot chain runs 2x longer on a shared one).
+#define EKF_PERSIST_FUSED_DYN_LDS (28 * 1024)
+void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
+    ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad);
+    if (!f->persist_attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  EKF_PERSIST_FUSED_DYN_LDS);
+        f->persist_attr_set = true;
+    }
+    GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+    if (m_on_device) ga.m_dev = f->info + 2;
+    const int nb2 = (m_pad / 64) * (f->ldp / 64);  // 64x64 transposing tiles of Wt
+    const int mb = m_pad / PB, rb = n_pad / PB + mb, ld = f->ld_aug;
+    PersistArgs pa;
+    pa.S = f->Saug, pa.lds = ld, pa.L = f->Laug, pa.ldl = ld, pa.Linv = f->Linv;
+    pa.mb = mb, pa.idb0 = mb + n_pad / PB, pa.nrows = mb + rb;
+    pa.info = f->info, pa.Lsign = f->Lsign;
+    pa.ready = f->sweep_sync;
+    pa.fin = f->sweep_sync + mb;
+    pa.gather_done = f->sweep_sync + mb + (mb + rb) * mb;
+    pa.abort_flag = pa.gather_done + 1;
+    pa.fused = 1, pa.gather_wgs = nb2;
+    pa.dbg = f->sweep_dbg;
+    pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+    pa.stall_wg = f->sweep_stall_wg >= 0 ? f->sweep_stall_wg + pa.gather_wgs + 2 : -1;  // (the hook counts owners from workgroup 1)
+    f->sweep_abort_word = pa.abort_flag;
+    if (!f->sweep_flags_clean) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
+    f->sweep_flags_clean = false;
+    hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + pa.gather_wgs + 2 + persist_helpers(mb, n_pad / PB)), dim3(256), EKF_PERSIST_FUSED_DYN_LDS,
+                       f->stream, pa, ga);
+    f->persistent_sweeps++;
+}
+
 void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, int m_pad, int n_pad, int ld, bool first_tile_done,
                        bool schur) {
     ProfScope ps(f, PC_CHOL, (double)m_pad * m_pad * m_pad / 3.0 + (double)(n_pad + m_pad / 2) * m_pad * m_pad +
@@ -1360,8 +1406,6 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int mb = m_pad / PB;
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
     const int idb0 = mb + n_pad / PB;
-    const bool flags_zeroed = f->sweep_flags_zeroed;  // (by gather_potrf_kernel, the launch in front, in the filter's update)
-    f->sweep_flags_zeroed = false;
     f->sweep_abort_word = nullptr;
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
@@ -1373,13 +1417,17 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.info = f->info, pa.Lsign = f->Lsign;
         pa.ready = f->sweep_sync;
         pa.fin = f->sweep_sync + mb;
-        pa.abort_flag = f->sweep_sync + mb + (mb + rb) * mb;
+        pa.gather_done = f->sweep_sync + mb + (mb + rb) * mb;
+        pa.abort_flag = pa.gather_done + 1;
+        pa.fused = 0, pa.gather_wgs = 0;
         pa.dbg = f->sweep_dbg;
         pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
         pa.stall_wg = f->sweep_stall_wg;
         f->sweep_abort_word = pa.abort_flag;  // the kernels behind this sweep leave the state alone if it is raised (launch_update)
-        if (!flags_zeroed) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
-        hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa);
+        // (the flags are zero already behind an update of this handle: its last GEMM zeroes them, launch_update)
+        if (!f->sweep_flags_clean) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
+        f->sweep_flags_clean = false;
+        hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + persist_helpers(mb, n_pad / PB)), dim3(256), 0, f->stream, pa, GatherArgs());
         f->persistent_sweeps++;
         return;
     }

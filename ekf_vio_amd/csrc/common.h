@@ -108,7 +108,10 @@ struct ekfvio_filter {
     int sweep_spin_limit = 0;         // > 0: looks per wait of the persistent sweep (test hook ekfvio_test_sweep_fault); 0: SWEEP_SPIN_LIMIT
     int sweep_stall_wg = -1;          // fault injection: this workgroup of the persistent launch never raises its flag
     const int* sweep_abort_word = nullptr;  // abort word of the persistent sweep enqueued last by launch_chol_sweep (null: another sweep)
-    bool sweep_flags_zeroed = false;  // gather_potrf_kernel has zeroed the flags for the sweep launch enqueued next
+    bool sweep_flags_clean = false;   // the persistent sweep's flags are zero for the launch enqueued next (zeroed by the last GEMM of the
+                                      // previous update, or by gather_potrf_kernel in front); otherwise the launcher enqueues a memset
+    int fuse_sweep = 1;               // 1: gather + first diagonal tile + sweep in ONE launch where the persistent sweep applies (EKFVIO_FUSE_SWEEP)
+    bool persist_attr_set = false;
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
     int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.
@@ -233,6 +236,8 @@ struct GemmEpi {
     int m = 0;                    // measurement rows (columns of K beyond it are padding)
     const int* m_dev = nullptr;   // the same in device memory (ekfvio_step_image), or null
     float* Kyp_out = nullptr;
+    int* zero_words = nullptr;    // modes 2-3: the persistent sweep's flags, zeroed by workgroup (0,0) for the NEXT update's sweep
+    int n_zero = 0;               // (everything but the abort word, which only ever goes up and retires the persistent path)
     const int* abort = nullptr;   // modes 1-3: abort word of the persistent sweep in front (non-zero: the factor is unfinished) --
                                   // the kernel then writes nothing: Sigma, mu and the frame counter stay as process(dt) left them
 };
@@ -305,6 +310,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
                        bool first_tile_done = false, bool schur = false);
 bool sweep_supports_schur(const ekfvio_filter* f, int m_pad);
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad);
+int persist_zero_words(int m_pad, int n_pad);
+void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 int live_handles_on(int device);  // api.hip: handles alive on that device in this process
 // K pruned, G = K R - T[:, idx], K y partial sums (one row of f->Wt per 64 measurement columns)
 void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);

@@ -945,8 +945,10 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
     // workgroups) the gather wants several workgroups per compute unit and the two stay separate.
     // T = Sigma - X A^-1 X^T and K = X A^-1 as Schur tiles of the sweep (no gain GEMM, no first Joseph GEMM, no (H Sigma)^T)
     const bool schur = m > 0 && sweep_supports_schur(f, m_pad);
+    // round 4: where the persistent sweep applies, the gather and the first tile are part of ITS launch (chol.hip, launch_persist_fused)
+    const bool fused_front = m > 0 && !schur && f->fuse_sweep && f->fuse_gather && sweep_is_persistent(f, m_pad, n_pad);
     bool fused_gather = false;
-    if (m > 0 && f->fuse_gather) {
+    if (m > 0 && f->fuse_gather && !fused_front) {
         const int gx = (std::max(ld, m_pad) + 255) / 256;
         fused_gather = 1 + gx * ((m_pad + GC * GCI - 1) / (GC * GCI)) + (schur ? 0 : (m_pad / 64) * (ld / 64)) <= f->num_cus;
     }
@@ -957,7 +959,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             if (m_on_device) bk.m_out = f->info + 2;
             hipLaunchKernelGGL(update_bookkeeping_kernel, dim3(1), dim3(1024), 0, f->stream, bk);
         }
-        if (m > 0) {
+        if (m > 0 && !fused_front) {
             if (fused_gather) {
                 // the gather and the factorisation of the first diagonal tile share one launch (chol.hip)
                 launch_gather_potrf(f, m, m_pad, n_pad, m_on_device, !schur);
@@ -994,7 +996,13 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
     } else if (m > 0) {
         // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
-        launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather);
+        if (fused_front) launch_persist_fused(f, m, m_pad, n_pad, m_on_device);
+        else launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather);
+        if (f->sweep_abort_word) {  // a persistent sweep ran: the update's last GEMM leaves its flags zero for the next one
+            e2.zero_words = f->sweep_sync;
+            e2.n_zero = persist_zero_words(m_pad, n_pad);
+            f->sweep_flags_clean = true;
+        }
         GemmEpi e1;
         e1.mode = 1;
         e1.inv_idx = f->inv_idx;

@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
             const int fi = *epi.frame_counter + 1;
             *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
         }
+        for (int e = threadIdx.x; e < epi.n_zero; e += 256 * GROUPS) epi.zero_words[e] = 0;  // the next update's sweep starts from zero flags
     }
     float* cp = C + (size_t)(j0 + wc * 32 + 4 * lk) * ldc + i;
     if (sym) {
@@ -872,6 +873,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             const int fi = *epi.frame_counter + 1;
             *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
         }
+        for (int e = threadIdx.x; e < epi.n_zero; e += 256) epi.zero_words[e] = 0;  // the next update's sweep starts from zero flags
     }
     float* cp = C + (size_t)jb * ldc + i0 + li;
     if (sym) {

@@ -18,6 +18,9 @@ v = list(st)
 names = ["operands, look, tile requests, publish", "pin", "panel solve", "update, block column 0", "factorisation", "stores"]
 mb = (2 * N + 63) // 64
 t0 = v[0]
+if v[1] and v[3]:  # fused launch (round 4): the chain workgroup's own prologue
+    print("fused launch, chain workgroup: tile (0,0) gather %d  factorisation %d  stores + ready[0] + wait for the gather workgroups %d  (step 0 starts %d cycles after the launch's first stamp)"
+          % (v[1] - v[0], v[2] - v[1], v[3] - v[2], v[32] - v[0]))
 for k in range(mb - 1):
     b = 32 + 8 * k
     e = [v[b + i] for i in range(6)] + [v[b + 8]]
