@@ -235,6 +235,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->frame_outputs = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_SWEEP");  // tuning knob: 0 = gather + first diagonal tile and the persistent sweep as two launches (round 3)
         if (e) f->fuse_sweep = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_PERSIST_EARLY");
+        if (e) f->persist_early = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_JOSEPH_SYM");  // experiment: 1 = only the lower triangle of the Joseph update's products, mirrored (common.h)
         if (e) f->joseph_sym = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches

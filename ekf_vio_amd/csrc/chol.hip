@@ -1390,6 +1390,7 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.fused = 1, pa.gather_wgs = nb2;
     pa.dbg = f->sweep_dbg;
     pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+    pa.early_sources = f->persist_early;
     pa.stall_wg = f->sweep_stall_wg >= 0 ? f->sweep_stall_wg + pa.gather_wgs + 2 : -1;  // (the hook counts owners from workgroup 1)
     f->sweep_abort_word = pa.abort_flag;
     if (!f->sweep_flags_clean) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
@@ -1422,6 +1423,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.fused = 0, pa.gather_wgs = 0;
         pa.dbg = f->sweep_dbg;
         pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+        pa.early_sources = f->persist_early;
         pa.stall_wg = f->sweep_stall_wg;
         f->sweep_abort_word = pa.abort_flag;  // the kernels behind this sweep leave the state alone if it is raised (launch_update)
         // (the flags are zero already behind an update of this handle: its last GEMM zeroes them, launch_update)
