@@ -218,7 +218,7 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     HIPC(f, dev_alloc(f->stream, &f->Lsign, (size_t)(f->m_cap / 64 > 256 ? f->m_cap / 64 : 256)));  // 256: the raw-solve test hook goes up to m = 16384
     {   // flags of the persistent sweep (chol_persist.inc): ready[mb] + fin[row blocks x mb] + abort word, below 16 block columns
         const size_t mb2 = (size_t)std::min(f->m_cap / 64, 16);
-        f->sweep_sync_words = std::max((size_t)1024, mb2 + (size_t)(f->ld_aug / 64 + 1) * mb2 + 8);  // (>= 1024: the test hooks sweep matrices that are not the filter's)
+        f->sweep_sync_words = std::max((size_t)1024, mb2 + 2 * (size_t)(f->ld_aug / 64 + 1) * mb2 + 8);  // (>= 1024: the test hooks sweep matrices that are not the filter's)
         HIPC(f, dev_alloc(f->stream, &f->sweep_sync, f->sweep_sync_words));
     }
     {
@@ -235,6 +235,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->frame_outputs = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_SWEEP");  // tuning knob: 0 = gather + first diagonal tile and the persistent sweep as two launches (round 3)
         if (e) f->fuse_sweep = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_PERSIST_GAIN");
+        if (e) f->persist_gain = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_EARLY");
         if (e) f->persist_early = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_JOSEPH_SYM");  // experiment: 1 = only the lower triangle of the Joseph update's products, mirrored (common.h)

@@ -1317,13 +1317,22 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
 
 // ready[mb] + fin[row blocks x mb] + the gather counter + the abort word (last: whoever zeroes the flags for the next sweep leaves it
 // alone, persist_zero_words), a multiple of 16 bytes
+// layout: ready[mb], fin[rows x mb], pan[rows x mb] (panel blocks of the X / identity rows, for the gain tiles formed inside the launch),
+// the gather counter, the abort word
 static size_t persist_flag_words(int m_pad, int n_pad) {
     const int mb = m_pad / PB, rows = 2 * mb + n_pad / PB;
-    return ((size_t)(mb + rows * mb + 2) + 3) & ~(size_t)3;
+    return ((size_t)(mb + 2 * rows * mb + 2) + 3) & ~(size_t)3;
 }
 int persist_zero_words(int m_pad, int n_pad) {
     const int mb = m_pad / PB, rows = 2 * mb + n_pad / PB;
-    return mb + rows * mb + 1;
+    return mb + 2 * rows * mb + 1;
+}
+static void persist_flag_pointers(ekfvio_filter* f, PersistArgs& pa, int mb, int rows) {
+    pa.ready = f->sweep_sync;
+    pa.fin = f->sweep_sync + mb;
+    pa.pan = pa.fin + rows * mb;
+    pa.gather_done = pa.pan + rows * mb;
+    pa.abort_flag = pa.gather_done + 1;
 }
 #define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, bool with_wt) {
@@ -1351,12 +1360,14 @@ static int persist_helpers(int mb, int nX) {
     for (int j = 1; j < mb; j++) h += (mb - j - (j == 1 ? 1 : 0)) + nX + (j + 1);
     return h;
 }
-bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
+// the shapes the persistent launch takes: 3 .. EKF_SWEEP_SPLIT_MB - 1 block columns, chain + owners co-resident
+static bool persist_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
-    const int rows = 2 * mb + n_pad / PB;
+    return mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus && persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
+}
+bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
-    return f->sweep_mode == 2 && !sweep_supports_schur(f, m_pad) && live_handles_on(f->device) <= 1 && mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus &&
-           persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
+    return f->sweep_mode == 2 && !sweep_supports_schur(f, m_pad) && live_handles_on(f->device) <= 1 && persist_shape(f, m_pad, n_pad);
 }
 
 // The update's whole front in ONE launch (round 4): the measurement gather, the first diagonal tile and the sweep behind it.
@@ -1383,11 +1394,14 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.S = f->Saug, pa.lds = ld, pa.L = f->Laug, pa.ldl = ld, pa.Linv = f->Linv;
     pa.mb = mb, pa.idb0 = mb + n_pad / PB, pa.nrows = mb + rb;
     pa.info = f->info, pa.Lsign = f->Lsign;
-    pa.ready = f->sweep_sync;
-    pa.fin = f->sweep_sync + mb;
-    pa.gather_done = f->sweep_sync + mb + (mb + rb) * mb;
-    pa.abort_flag = pa.gather_done + 1;
+    persist_flag_pointers(f, pa, mb, mb + rb);
     pa.fused = 1, pa.gather_wgs = nb2;
+    // the transposing workgroups stay and form the gain while the sweep runs, as long as (nearly) every workgroup of the launch finds a
+    // compute unit at once: they hold theirs to the end
+    const int total = 1 + nb2 + 2 + persist_helpers(mb, n_pad / PB);
+    pa.gain = (f->persist_gain && !f->joseph_sym && total <= f->num_cus + 8) ? 1 : 0;
+    pa.K = f->Km, pa.ldk = f->ldp;
+    f->gain_in_sweep = pa.gain != 0;
     pa.dbg = f->sweep_dbg;
     pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
     pa.early_sources = f->persist_early;
@@ -1408,6 +1422,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int rb = n_pad / PB + mb;        // extra row blocks: X then I
     const int idb0 = mb + n_pad / PB;
     f->sweep_abort_word = nullptr;
+    f->gain_in_sweep = false;
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     if (!schur && sweep_is_persistent(f, m_pad, n_pad)) {
@@ -1416,11 +1431,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.S = Saug, pa.lds = ld, pa.L = Laug, pa.ldl = ld, pa.Linv = Linv;
         pa.mb = mb, pa.idb0 = idb0, pa.nrows = mb + rb;
         pa.info = f->info, pa.Lsign = f->Lsign;
-        pa.ready = f->sweep_sync;
-        pa.fin = f->sweep_sync + mb;
-        pa.gather_done = f->sweep_sync + mb + (mb + rb) * mb;
-        pa.abort_flag = pa.gather_done + 1;
-        pa.fused = 0, pa.gather_wgs = 0;
+        persist_flag_pointers(f, pa, mb, mb + rb);
+        pa.fused = 0, pa.gather_wgs = 0, pa.gain = 0, pa.K = nullptr, pa.ldk = 0;
         pa.dbg = f->sweep_dbg;
         pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
         pa.early_sources = f->persist_early;
@@ -1566,6 +1578,17 @@ bool sweep_supports_schur(const ekfvio_filter* f, int m_pad) {
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
                             float* scratch, int ldk, int refine, const GemmEpi* epi) {
     ProfScope ps(f, PC_SOLVE, (refine ? 3.0 : 1.0) * n * (double)m_pad * m_pad);
+    if (!refine && !epi && f->persist_gain && persist_shape(f, m_pad, n_pad)) {
+        // a shape the persistent launch takes when the handle is alone on its device (this call: it is not, or EKFVIO_SWEEP=0): the
+        // tile kernel whose arithmetic that launch's in-sweep gain shares (chol_persist.inc, gain_tile), so that a sequence gives the
+        // same bits whichever sweep its updates take (eight handles on one GPU against each one's solo run, tests/test_gpu_shapes.py)
+        PersistArgs pa = PersistArgs();
+        pa.L = const_cast<float*>(Laug), pa.ldl = ld;
+        pa.mb = m_pad / PB, pa.idb0 = m_pad / PB + n_pad / PB;
+        pa.K = K, pa.ldk = ldk;
+        hipLaunchKernelGGL(gain_tiles_kernel, dim3((n_pad / PB) * pa.mb), dim3(256), 0, f->stream, pa);
+        return;
+    }
     const float* Lf = Laug;
     const float* Y = Laug + m_pad;
     const float* LinvT = Laug + m_pad + n_pad;

@@ -1011,7 +1011,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         e1.ldg = ld;
         e1.abort = e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: both GEMMs write nothing
         if (!f->joseph_sym) {
-            launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
+            if (!f->gain_in_sweep) launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
             // The two P-update GEMMs, back to back (one profiler scope, two launches), both triangles:
             //   T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place; also G and K*y (column n)
             //   Sigma' = T + G*K^T, pruned (:594-596, :625); workgroup (0,0) finishes the mean
