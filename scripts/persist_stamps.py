@@ -34,4 +34,9 @@ for j in range(2, mb - 1):
     if v[b]:  # (these run on other XCDs: their s_memtime counters have other origins, only differences mean something)
         print("helper of tile (%d,%d), its last step (what the chain's step %d waits for): " % (j + 1, j, j)
               + "  ".join("%s %5d" % (hn[q], v[b + q + 1] - v[b + q]) for q in range(5)))
+sn = ["wait sources", "load sources", "wait readyA", "L_kk + stage A", "partial product", "wait ready", "stage B + tail"]
+for j in range(2, mb - 1):
+    b = 760 + 8 * (j & 7)
+    if v[b] and v[b + 7]:
+        print("staged last step of tile (%d,%d): " % (j + 1, j) + "  ".join("%s %5d" % (sn[q], v[b + q + 1] - v[b + q]) for q in range(7)))
 print("wavefront 0's early look at the step's two flags (100 = both up, 101 = not yet):", [int(v[500 + k]) for k in range(1, mb - 1)])
