@@ -516,12 +516,21 @@ def main():
         # PCIe-inclusive rate (never `value`): the per-call boundary with host-resident measurements,
         # one ekfvio_process + one synchronising ekfvio_update per step
         nh = 100
+        import gc
+        gc.collect()
+        gc.disable()  # (with torch imported a generation-2 collection is a 40-70 ms pause: seen as one outlier call in some runs)
         th = time.perf_counter()
+        per_call = []
         for z_h, R_h, p_h in fr[-nh:]:
+            t1 = time.perf_counter()
             g.process(dt)
             g.updateWithFeaturePositions(z_h, R_h, p_h)
+            per_call.append(time.perf_counter() - t1)
         g.synchronize()
         extra["pcie_inclusive_steps_per_s"] = nh / (time.perf_counter() - th)
+        gc.enable()
+        extra["pcie_inclusive_us_per_step"] = {"median": 1e6 * float(np.median(per_call)), "p90": 1e6 * float(np.percentile(per_call, 90)),
+                                               "max": 1e6 * float(np.max(per_call)), "argmax": int(np.argmax(per_call)), "sweeps": g.sweep_counts()}
         # The same GEMM kernel family at the N=1024 stress shape (3094 x 3094 x 2048), where a launch is many rounds of
         # workgroups instead of one: what the kernel reaches when the shape lets it (the N=256 figure above is bounded
         # by one workgroup's latency plus the kernel boundary)
@@ -541,12 +550,13 @@ def main():
         if "cholesky" in extra["stage_us_per_step"]:
             us_sweep = extra["stage_us_per_step"]["cholesky"]
             extra["roofline_sweep"] = {"bound": "latency (sequential pivot chain of one workgroup; DESIGN.md section 3)",
-                                       "kernel": "Cholesky sweep behind the first diagonal tile (chol_persist_kernel where it applies, else one launch per block step)",
+                                       "kernel": "gather + Cholesky sweep + gain tiles in one persistent launch (chol_persist_kernel where it applies, else gather, one launch per block step, gain kernel)",
                                        "flops_per_step": fl["cholesky_sweep"], "stage_us": us_sweep,
                                        "achieved": fl["cholesky_sweep"] / (us_sweep * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                        "frac": fl["cholesky_sweep"] / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                        "note": "event-bracketed stage time of the eager, per-stage timed run (includes a few us of launch gaps); "
-                                               "in-kernel stamps: profiles/r03_cholesky_phase_stamps.txt"}
+                                               "since round 4 the stage is ONE launch that also holds the measurement gather, the first diagonal tile and the gain's tiles "
+                                               "(chol_persist_kernel, fused); in-kernel stamps: profiles/r04_cholesky_phase_stamps.txt"}
     g.close()
     if rank == 0 and world == 1 and not args.no_full_loop:
         try:
