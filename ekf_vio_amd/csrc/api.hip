@@ -235,6 +235,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->frame_outputs = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_SWEEP");  // tuning knob: 0 = gather + first diagonal tile and the persistent sweep as two launches (round 3)
         if (e) f->fuse_sweep = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_PERSIST_OVERSUB");
+        if (e) f->persist_oversub = atoi(e);
         e = getenv("EKFVIO_PERSIST_GAIN");
         if (e) f->persist_gain = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_EARLY");

@@ -1360,10 +1360,31 @@ static int persist_helpers(int mb, int nX) {
     for (int j = 1; j < mb; j++) h += (mb - j - (j == 1 ? 1 : 0)) + nX + (j + 1);
     return h;
 }
-// the shapes the persistent launch takes: 3 .. EKF_SWEEP_SPLIT_MB - 1 block columns, chain + owners co-resident
+// The shapes the persistent launch takes: 3 .. EKF_SWEEP_SPLIT_MB - 1 block columns.  Up to round 3: chain + owners co-resident
+// (1 + tiles <= compute units).  Round 4: up to EKF_PERSIST_OVERSUB x that.  An owner waits only for workgroups with a LOWER block index
+// (the chain is workgroup 0, the owners are numbered block column by block column, and a tile's panel sources lie in earlier columns), so
+// with workgroups dispatched in index order -- what the hardware does, though HIP does not promise it -- the resident ones can always
+// finish, and the later columns' owners take over their compute units and catch up (their flags are all up: ~10 k cycles per step
+// against the chain's ~15.5 k).  N = 400 (params/fast_with_insight.yaml: 13 block columns, 407 owners) runs the sweep in one launch
+// this way.  Should the order ever not hold, the bounded waits end the launch and the update is run again per step (EKFVIO_EABORTED).
+// Measured (profiles/r04_oversubscribed_persistent_sweep.txt): bit-identical, the sweep itself 155.7 -> 121.2 us at N = 400, but the gain
+// kernel behind it then runs 2x longer on operands the persistent launch has left in other XCDs' L2s; +2.9 % per step in all.  Off by
+// default (1); EKFVIO_PERSIST_OVERSUB=2 turns it on, tests/test_gpu_parity.py exercises it.
+#ifndef EKF_PERSIST_OVERSUB
+#define EKF_PERSIST_OVERSUB 1
+#endif
 static bool persist_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
-    return mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= f->num_cus && persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
+    const int over = f->persist_oversub > 0 ? f->persist_oversub : EKF_PERSIST_OVERSUB;
+    return mb >= 3 && mb < EKF_SWEEP_SPLIT_MB && 1 + persist_helpers(mb, n_pad / PB) <= (over > 1 ? over : 1) * f->num_cus &&
+           persist_flag_words(m_pad, n_pad) <= f->sweep_sync_words;
+}
+// ... and of those, the shapes whose gain is formed inside the fused launch: (nearly) every workgroup of that launch finds a compute unit
+// at once (the transposing / gain workgroups hold theirs to the end).  Behind every other sweep of such a shape gain_tiles_kernel runs
+// the same arithmetic; all other shapes take the gain GEMM, whichever sweep ran.
+static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
+    const int mb = m_pad / PB;
+    return persist_shape(f, m_pad, n_pad) && 1 + mb * (f->ldp / 64) + 2 + persist_helpers(mb, n_pad / PB) <= f->num_cus + 8;
 }
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
@@ -1398,8 +1419,7 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.fused = 1, pa.gather_wgs = nb2;
     // the transposing workgroups stay and form the gain while the sweep runs, as long as (nearly) every workgroup of the launch finds a
     // compute unit at once: they hold theirs to the end
-    const int total = 1 + nb2 + 2 + persist_helpers(mb, n_pad / PB);
-    pa.gain = (f->persist_gain && !f->joseph_sym && total <= f->num_cus + 8) ? 1 : 0;
+    pa.gain = (f->persist_gain && !f->joseph_sym && gain_in_sweep_shape(f, m_pad, n_pad)) ? 1 : 0;
     pa.K = f->Km, pa.ldk = f->ldp;
     f->gain_in_sweep = pa.gain != 0;
     pa.dbg = f->sweep_dbg;
@@ -1578,7 +1598,7 @@ bool sweep_supports_schur(const ekfvio_filter* f, int m_pad) {
 void launch_gain_from_sweep(ekfvio_filter* f, const float* Laug, int m_pad, int n_pad, int ld, int n, float* K,
                             float* scratch, int ldk, int refine, const GemmEpi* epi) {
     ProfScope ps(f, PC_SOLVE, (refine ? 3.0 : 1.0) * n * (double)m_pad * m_pad);
-    if (!refine && !epi && f->persist_gain && persist_shape(f, m_pad, n_pad)) {
+    if (!refine && !epi && f->persist_gain && gain_in_sweep_shape(f, m_pad, n_pad)) {
         // a shape the persistent launch takes when the handle is alone on its device (this call: it is not, or EKFVIO_SWEEP=0): the
         // tile kernel whose arithmetic that launch's in-sweep gain shares (chol_persist.inc, gain_tile), so that a sequence gives the
         // same bits whichever sweep its updates take (eight handles on one GPU against each one's solo run, tests/test_gpu_shapes.py)

@@ -112,6 +112,7 @@ struct ekfvio_filter {
                                       // previous update, or by gather_potrf_kernel in front); otherwise the launcher enqueues a memset
     int fuse_sweep = 1;               // 1: gather + first diagonal tile + sweep in ONE launch where the persistent sweep applies (EKFVIO_FUSE_SWEEP)
     bool persist_attr_set = false;
+    int persist_oversub = 0;          // > 0 (EKFVIO_PERSIST_OVERSUB): owner workgroups allowed per compute unit's worth of the persistent launch (chol.hip, persist_shape)
     int persist_gain = 1;             // 1 (EKFVIO_PERSIST_GAIN=0 turns it off): the gain's tiles are formed inside the fused persistent launch (chol_persist.inc)
     bool gain_in_sweep = false;       // the launch enqueued last did (launch_update then skips the gain kernel)
     int persist_early = 1;            // 1 (EKFVIO_PERSIST_EARLY=0 turns it off): owners fetch their panel sources in front of the wait for ready[k] (chol_persist.inc)

@@ -578,19 +578,23 @@ def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
     assert relf(out["1"]["Sigma"], out["0"]["Sigma"]) < 2e-5 and maxabs(out["1"]["base_mu"], out["0"]["base_mu"]) < 2e-5
 
 
-@pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (300, 0), (300, 11), (100, 3), (64, 0), (40, 5), (33, 0)])
+@pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (300, 0), (300, 11), (100, 3), (64, 0), (40, 5), (33, 0), (400, 0), (400, 23)])
 def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkeypatch, N, fails):
     """The default sweep (chol_persist.inc): everything behind the first diagonal tile in ONE launch -- the chain workgroup
     keeps L_kk in LDS from step to step, every other tile has an owner workgroup that keeps it in registers for the whole
     sweep, hand-offs are write-through stores behind per-tile flags.  Same per-tile arithmetic in the same order as one
     launch per block step (EKFVIO_SWEEP=0): every bit of the state must agree, per call and in graph replay, with ragged measurement
-    counts and with one, two, four, eight and ten block columns (N = 300: 233 owner workgroups)."""
+    counts and with one, two, four, eight and ten block columns (N = 300: 233 owner workgroups), and -- round 4 -- with more owner
+    workgroups than compute units (EKFVIO_PERSIST_OVERSUB=2; N = 400, params/fast_with_insight.yaml: thirteen block columns, 407 owners):
+    the later block columns' owners start when the earlier ones' have finished and catch up."""
     sc = Scenario(N, seed=11)
     fr = list(sc.frames(5))
     for s, (z, R, p) in enumerate(fr):
         for q in range(fails):
             p[(7 * q + 3 * s + 1) % N] = 0
     out = {}
+    if N > 300:
+        monkeypatch.setenv("EKFVIO_PERSIST_OVERSUB", "2")  # (off by default: measured, +2.9 % only -- chol.hip, persist_shape)
     for mode in ("0", "2"):
         monkeypatch.setenv("EKFVIO_SWEEP", mode)
         for replay in (False, True):
