@@ -1315,10 +1315,9 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps, (w && atoi(w)) ? 2 : 1);
 }
 
-// ready[mb] + fin[row blocks x mb] + the gather counter + the abort word (last: whoever zeroes the flags for the next sweep leaves it
-// alone, persist_zero_words), a multiple of 16 bytes
-// layout: ready[mb], fin[rows x mb], pan[rows x mb] (panel blocks of the X / identity rows, for the gain tiles formed inside the launch),
-// the gather counter, the abort word
+// layout: ready[mb], fin[rows x mb], pan[rows x mb] (panel blocks of the X / identity rows, for the gain tiles formed inside the
+// launch), one spare word, the abort word (last: whoever zeroes the flags for the next sweep leaves it alone, persist_zero_words);
+// a multiple of 16 bytes
 static size_t persist_flag_words(int m_pad, int n_pad) {
     const int mb = m_pad / PB, rows = 2 * mb + n_pad / PB;
     return ((size_t)(mb + 2 * rows * mb + 2) + 3) & ~(size_t)3;
@@ -1331,8 +1330,7 @@ static void persist_flag_pointers(ekfvio_filter* f, PersistArgs& pa, int mb, int
     pa.ready = f->sweep_sync;
     pa.fin = f->sweep_sync + mb;
     pa.pan = pa.fin + rows * mb;
-    pa.gather_done = pa.pan + rows * mb;
-    pa.abort_flag = pa.gather_done + 1;
+    pa.abort_flag = pa.pan + rows * mb + 1;
 }
 #define EKF_GATHER_POTRF_LDS (84 * 1024)  // > half of a compute unit's 160 KB: one workgroup per compute unit
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, bool with_wt) {
