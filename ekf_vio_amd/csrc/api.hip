@@ -216,8 +216,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Lsign, (size_t)(f->m_cap / 64 > 256 ? f->m_cap / 64 : 256)));  // 256: the raw-solve test hook goes up to m = 16384
-    {   // flags of the persistent sweep (chol_persist.inc): ready[mb] + fin[row blocks x mb] + abort word, below 16 block columns
-        const size_t mb2 = (size_t)std::min(f->m_cap / 64, 16);
+    {   // flags of the persistent sweeps (chol_persist.inc, chol_persist_la.inc): ready[mb] + 2 x [row blocks x mb] + abort word
+        const size_t mb2 = (size_t)(f->m_cap / 64);
         f->sweep_sync_words = std::max((size_t)1024, mb2 + 2 * (size_t)(f->ld_aug / 64 + 1) * mb2 + 8);  // (>= 1024: the test hooks sweep matrices that are not the filter's)
         HIPC(f, dev_alloc(f->stream, &f->sweep_sync, f->sweep_sync_words));
     }

@@ -1031,231 +1031,6 @@ __global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ S, i
     }
 }
 
-// The split sweep's block step with the panel solve folded in (many tiles per step, mb >= EKF_SWEEP_SPLIT_MB).
-// The split sweep used to be two launches per block step: chol_panel_kernel(k) for the panel blocks L_ik, then the
-// tiles.  At N = 1024 the panel launch is a few dozen workgroups and 5 us of latency, 32 times per update, with the
-// chip idle.  Here launch l does
-//   near tiles  (i, l+1), every row block i below the diagonal and all extra rows: step l-1's update from the STORED
-//               panel blocks L_i,l-1, L_l+1,l-1, then step l's from panel blocks the tile solves itself (L_il = A_il
-//               L_ll^-T, stored for the next launch; A_il is final: column l was the near column of launch l-1);
-//               tile (l+1, l+1) is the chain: updated, factored, stored, as in chol_step_kernel;
-//   far tiles   (i, j), j = l+2, l+4, ...: steps l-2 AND l-1 from stored panel blocks.  A column is visited every second
-//               launch and takes two steps per visit, so the trailing matrix -- whose read-modify-write out of Infinity
-//               Cache is what bounds these launches -- is read and written half as often for the same arithmetic.  Column
-//               j's last far visit is launch j-2 (steps j-4, j-3); launch j-1 is its near visit (steps j-2, j-1).
-// Every tile still receives its updates in ascending step order, one subtraction per step: bit-identical to the
-// two-launch form.  Far tiles need no solve, near tiles fetch the solve's operands into registers and then re-use
-// L_ll's LDS tile for their second row block, so the kernel stays at two LDS tiles (four workgroups per compute unit).
-__global__ __launch_bounds__(256, 4) void chol_step_la_kernel(float* __restrict__ S, int lds, float* __restrict__ L, int ldl,
-                                                           float* __restrict__ Linv, int l, int mb, int rb, int idb0, int* info,
-                                                           unsigned long long* Lsign) {
-    __shared__ __attribute__((aligned(16))) float Ti[PB * PLD];
-    __shared__ __attribute__((aligned(16))) float Tj[PB * PLD];
-    __shared__ float Tinv[INV_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave & 1, wc = wave >> 1;
-    const int r = mb - 1 - l;       // block columns right of l
-    const int nnear = r + rb;       // column l+1: the chain, r-1 row blocks of A below it, the extra row blocks
-    int t = blockIdx.x, i, j;
-    const bool near = t < nnear;
-    if (near) {
-        j = l + 1;
-        i = (t < r) ? l + 1 + t : mb + (t - r);
-    } else {
-        t -= nnear;
-        j = l + 2;  // columns l+2, l+4, ...: mb - j row blocks of A from the diagonal down, then the extra rows
-        while (t >= mb - j + rb) {
-            t -= mb - j + rb;
-            j += 2;
-        }
-        i = (t < mb - j) ? j + t : mb + (t - (mb - j));
-    }
-    const int ic = i - idb0;                       // identity block row c: block (i,k) is zero for k < c
-    const bool has0 = l >= 1 && !(ic > l - 1);      // step l-1 reaches this row block
-    const bool has1 = near && !(ic > l);            // step l does
-    if (!has0 && !has1) return;
-    const bool chain = near && i == j;
-    unsigned long long neg0 = 0ull, neg1 = 0ull;
-    float* Sij = S + (size_t)j * PB * lds + (size_t)i * PB;
-    const int rw = wr * 32 + (lane & 31);
-    f32x16 up0;
-#pragma unroll
-    for (int q = 0; q < 16; q++) up0[q] = 0.f;
-
-    if (!near) {  // far tile: steps l-2 (if it reaches this row block) and l-1 from stored panel blocks
-        const bool hasa = l >= 2 && !(ic > l - 2);
-        f32x16 upa;
-#pragma unroll
-        for (int q = 0; q < 16; q++) upa[q] = 0.f;
-        if (hasa) {
-            unsigned long long nega = sign_mask_request(Lsign + l - 2);
-            load_tile(Ti, L + (size_t)(l - 2) * PB * ldl + (size_t)i * PB, ldl, tid);
-            if (i != j) load_tile(Tj, L + (size_t)(l - 2) * PB * ldl + (size_t)j * PB, ldl, tid);
-            __syncthreads();
-            nega = sign_mask_value(nega);
-            const float* Ba = (i != j) ? Tj : Ti;
-            upa = (nega == 0ull) ? mma64(Ti, 1, PLD, Ba, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Ba, 1, PLD, wr, wc, lane, nega);
-            __syncthreads();
-        }
-        neg0 = sign_mask_request(Lsign + l - 1);
-        load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)i * PB, ldl, tid);
-        if (i != j) load_tile(Tj, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
-        __syncthreads();
-        neg0 = sign_mask_value(neg0);
-        const float* Bj = (i != j) ? Tj : Ti;
-        float tv[16];  // the target tile's round trip runs under the product
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            tv[q] = Sij[(size_t)c * lds + rw];
-        }
-        const f32x16 up = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Bj, 1, PLD, wr, wc, lane, neg0);
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const float a = hasa ? tv[q] - upa[q] : tv[q];
-            Sij[(size_t)c * lds + rw] = a - up[q];
-        }
-        return;
-    }
-
-    if (!chain) {
-        // ---- near tile below the diagonal / extra row ----
-        if (has0) {
-            neg0 = sign_mask_request(Lsign + l - 1);
-            load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)i * PB, ldl, tid);
-            load_tile(Tj, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
-            __syncthreads();
-            neg0 = sign_mask_value(neg0);
-            up0 = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane, neg0);
-            __syncthreads();
-        }
-        // L_ll and its inverses -> the solve's operands in registers; then the two row blocks take the tiles' place
-        neg1 = sign_mask_request(Lsign + l);
-        load_tile(Tj, L + (size_t)l * PB * ldl + (size_t)l * PB, ldl, tid);
-        load_inv(Tinv, Linv + (size_t)l * PB * PB, tid);
-        __syncthreads();
-        neg1 = sign_mask_value(neg1);
-        TriOps ops;
-        tri_solve_preload(ops, Tj, Tinv, lane);
-        tri_solve_pin(ops);
-        __syncthreads();
-        load_tile(Ti, S + (size_t)l * PB * lds + (size_t)i * PB, lds, tid);
-        load_tile(Tj, S + (size_t)l * PB * lds + (size_t)j * PB, lds, tid);
-        __syncthreads();
-        {
-            float* const tt[2] = {Ti, Tj};
-            f32x4 x[2][4];
-            tri_solve_load_x<2>(x, tt, wave, lane);
-            tri_solve_run<2>(x, tt, ops, wave, lane);
-        }
-        __syncthreads();
-        store_tile(Ti, L + (size_t)l * PB * ldl + (size_t)i * PB, ldl, tid);  // unsigned: read back as an operand (sign_irows_kernel)
-        float tv[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            tv[q] = Sij[(size_t)c * lds + rw];
-        }
-        const f32x16 up1 = (neg1 == 0ull) ? mma64(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Tj, 1, PLD, wr, wc, lane, neg1);
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const float a = has0 ? tv[q] - up0[q] : tv[q];
-            Sij[(size_t)c * lds + rw] = a - up1[q];
-        }
-        return;
-    }
-
-    // ---- the chain: tile (l+1, l+1) ----
-    // everything it reads from memory is requested at once: the stored block L_j,l-1 -> Ti, L_ll -> Tj (stays: i == j
-    // leaves the second row-block tile unused), and A_jl into registers, written to Ti once step l-1's product has read it
-    if (has0) neg0 = sign_mask_request(Lsign + l - 1);
-    neg1 = sign_mask_request(Lsign + l);
-    float4 areg[4];
-    {
-        const float* A = S + (size_t)l * PB * lds + (size_t)j * PB;
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int e = tid + it * 256;
-            areg[it] = *reinterpret_cast<const float4*>(A + (size_t)(e >> 4) * lds + (e & 15) * 4);
-        }
-    }
-    if (has0) load_tile(Ti, L + (size_t)(l - 1) * PB * ldl + (size_t)j * PB, ldl, tid);
-    load_tile(Tj, L + (size_t)l * PB * ldl + (size_t)l * PB, ldl, tid);
-    load_inv(Tinv, Linv + (size_t)l * PB * PB, tid);
-    __syncthreads();
-    if (has0) neg0 = sign_mask_value(neg0);
-    neg1 = sign_mask_value(neg1);
-    if (has0) {
-        up0 = (neg0 == 0ull) ? mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane, neg0);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int e = tid + it * 256;
-        *reinterpret_cast<float4*>(Ti + (e >> 4) * PLD + (e & 15) * 4) = areg[it];
-    }
-    __syncthreads();
-    tri_solve_fwd(Ti, Tj, Tinv, wave, lane);  // L_jl = A_jl L_ll^-T
-    __syncthreads();
-    float tgt[16];
-    {   // target tile requested before the product, used behind it (see chol_step_kernel)
-        const unsigned off0 = ((unsigned)(wc * 32 + 4 * (lane >> 5)) * (unsigned)lds + (unsigned)rw) * 4u;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const unsigned off = off0 + (unsigned)((q & 3) + 8 * (q >> 2)) * (unsigned)lds * 4u;
-            tgt[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Sij) + off);
-        }
-    }
-    const f32x16 up1 = (neg1 == 0ull) ? mma64(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane) : mma64_signed(Ti, 1, PLD, Ti, 1, PLD, wr, wc, lane, neg1);
-    float* Tl = Tj;  // every wavefront is past its substitution (barrier above): L_ll's tile takes the updated diagonal tile
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        const float a = has0 ? tgt[q] - up0[q] : tgt[q];
-        Tl[c * PLD + rw] = a - up1[q];
-    }
-    __syncthreads();
-    float* Ldst = L + (size_t)j * PB * ldl + (size_t)j * PB;
-    float* Idst = Linv + (size_t)(l + 1) * PB * PB;
-    float* Pdst = L + (size_t)l * PB * ldl + (size_t)j * PB;
-    const float* Tl_c = Tl;
-    const float* Ti_c = Ti;
-    const float* Tinv_c = Tinv;
-    auto idle = [&](auto pc, int wv) {  // stores under the pivot chain (see chol_step_kernel)
-        constexpr int p = decltype(pc)::value;
-        if constexpr (p == 2) {
-            if (wv >= 2) store_cols<0, 32, 128, true>(Tl_c, Ldst, ldl, tid - 128);
-        } else if constexpr (p == 3) {
-            store_cols<32, 16, 192, true>(Tl_c, Ldst, ldl, tid - 64);
-            store_inv_blocks(Tinv_c, Idst, 0, tid - 64);
-            store_cols<0, 64, 192, false>(Ti_c, Pdst, ldl, tid - 64);
-        }
-    };
-    const bool bad = potrf64_lds<EKF_POTRF_FV>(Tl, Tinv, tid, nullptr, idle);
-    unsigned long long negn = 0ull;
-    if (bad) {  // workgroup-uniform, rare: the updated tile is formed again and factored as U S U^T
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int c = wc * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const float a = has0 ? Sij[(size_t)c * lds + rw] - up0[q] : Sij[(size_t)c * lds + rw];
-            Tl[c * PLD + rw] = a - up1[q];
-        }
-        negn = potrf64_signed(Tl, Tinv, tid);
-        store_tile_lower(Tl, Ldst, ldl, tid);
-        store_inv(Tinv, Idst, tid);
-    } else {
-        store_cols<48, 16, 256, true>(Tl_c, Ldst, ldl, tid);
-        if (tid < 64) store_inv_blocks(Tinv_c, Idst, 3, tid);
-    }
-    if (tid == 0) {
-        Lsign[l + 1] = negn;
-        if (bad) atomicOr(info, 1);
-    }
-}
-
 // Block column k of the panel: L_ik = A_ik L_kk^-T for the row blocks below the diagonal (A rows k+1 .. mb-1, `na` of
 // them; na = 0 for the last block column) and the extra row blocks (X, I).
 // sign_irows: the panel blocks of the identity rows are stored with the block column's signs applied (what the gain GEMM
@@ -1303,6 +1078,7 @@ __global__ __launch_bounds__(256) void sign_irows_kernel(float* __restrict__ L, 
 #define SWEEP_SPIN_LIMIT (1 << 22)
 
 #include "chol_persist.inc"
+#include "chol_persist_la.inc"
 
 }  // namespace
 
@@ -1383,6 +1159,33 @@ static bool persist_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
 static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     return persist_shape(f, m_pad, n_pad) && 1 + mb * (f->ldp / 64) + 2 + persist_helpers(mb, n_pad / PB) <= f->num_cus + 8;
+}
+// The split sweep as one persistent launch (chol_persist_la.inc): the grid is every workgroup slot of the device (the occupancy
+// query's workgroups per compute unit x compute units: all must be resident, they wait for each other), admitted when the round-robin
+// deal gives a workgroup at most LA_MAX_TILES tiles and the flags fit; 0 = run the rounds as launches.
+// EKFVIO_SWEEP_LA_PERSIST=0 (diagnostic) keeps the launches.
+static int la_persist_grid(ekfvio_filter* f, int m_pad, int n_pad) {
+    static const bool on = getenv("EKFVIO_SWEEP_LA_PERSIST") ? atoi(getenv("EKFVIO_SWEEP_LA_PERSIST")) != 0 : false;  // (work in progress: opt-in)
+    const int mb = m_pad / PB, rb = n_pad / PB + mb;
+    if (!on || f->sweep_mode != 2 || mb < EKF_SWEEP_SPLIT_MB || live_handles_on(f->device) > 1 ||
+        persist_flag_words(m_pad, n_pad) > f->sweep_sync_words) {
+        if (getenv("EKFVIO_DEBUG_LA"))
+            fprintf(stderr, "la_persist: off (on %d mode %d mb %d live %d words %zu / %zu)\n", (int)on, f->sweep_mode, mb, live_handles_on(f->device),
+                    persist_flag_words(m_pad, n_pad), f->sweep_sync_words);
+        return 0;
+    }
+    if (f->la_persist_occupancy < 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(chol_persist_la_kernel), 256, 0) != hipSuccess) nb = 0;
+        f->la_persist_occupancy = nb;
+        if (getenv("EKFVIO_DEBUG_LA")) fprintf(stderr, "la_persist: occupancy %d cus %d\n", nb, f->num_cus);
+    }
+    const int grid = f->la_persist_occupancy * f->num_cus;
+    int tiles = 0;  // far owners' tiles: block columns >= 3
+    for (int j = 3; j < mb; j++) tiles += mb - j + rb;
+    const int general = grid - 4 - (mb + rb - 2);  // without the chain's compute unit and the row workers
+    if (general < 64 || (tiles + general - 1) / general > LA_MAX_TILES) return 0;
+    return grid;
 }
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
@@ -1486,13 +1289,35 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     // EKFVIO_SWEEP_LA=0 (diagnostic): the two-launch split sweep (panel launch + tile launch per block step)
     static const bool la_env = getenv("EKFVIO_SWEEP_LA") ? atoi(getenv("EKFVIO_SWEEP_LA")) != 0 : true;
     if (split && la_env) {
-        for (int l = 0; l + 1 < mb; l++) {
-            const int r = mb - 1 - l;
-            int far = 0;  // columns l+2, l+4, ... from the diagonal down plus the extra rows
-            if (l >= 1)
-                for (int j = l + 2; j < mb; j += 2) far += mb - j + rb;
-            hipLaunchKernelGGL(chol_step_la_kernel, dim3(r + rb + far), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, l, mb, rb,
-                               idb0, f->info, f->Lsign);
+        LaArgs la;
+        la.S = Saug, la.lds = ld, la.L = Laug, la.ldl = ld, la.Linv = Linv;
+        la.mb = mb, la.rb = rb, la.idb0 = idb0, la.info = f->info, la.Lsign = f->Lsign;
+        const int la_grid = la_persist_grid(f, m_pad, n_pad);
+        if (la_grid > 0) {
+            // ONE launch for all block steps (chol_persist_la.inc): tile owners, hand-offs through flags
+            PersistArgs pa;
+            persist_flag_pointers(f, pa, mb, mb + rb);
+            LaSync y;
+            y.ready = pa.ready, y.near_done = pa.fin, y.far_done = pa.pan, y.abort_flag = pa.abort_flag;
+            y.nrows = mb + rb;
+            y.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+            y.stall_wg = f->sweep_stall_wg;
+            y.dbg = f->sweep_dbg;
+            y.ticket = pa.fin + (mb - 1) * (mb + rb);  // (the unused tail of the near_done block: zeroed with the flags)
+            y.chain_key = y.ticket + 1;
+            f->sweep_abort_word = pa.abort_flag;
+            if (!f->sweep_flags_clean) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
+            f->sweep_flags_clean = false;
+            hipLaunchKernelGGL(chol_persist_la_kernel, dim3(la_grid), dim3(256), 0, f->stream, la, y);
+            f->persistent_sweeps++;
+        } else {
+            for (int l = 0; l + 1 < mb; l++) {
+                const int r = mb - 1 - l;
+                int far = 0;  // columns l+2, l+4, ... from the diagonal down plus the extra rows
+                if (l >= 1)
+                    for (int j = l + 2; j < mb; j += 2) far += mb - j + rb;
+                hipLaunchKernelGGL(chol_step_la_kernel, dim3(r + rb + far), dim3(256), 0, f->stream, la, l);
+            }
         }
         hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0, f->Lsign, 0);
         hipLaunchKernelGGL(sign_irows_kernel, dim3((m_pad + 255) / 256, mb), dim3(256), 0, f->stream, Laug, ld, idb0 * PB, m_pad,
