@@ -237,6 +237,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->fuse_sweep = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_OVERSUB");
         if (e) f->persist_oversub = atoi(e);
+        e = getenv("EKFVIO_SWEEP_LA_PERSIST");  // experiment: 1 = the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
+        if (e) f->la_persist = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_GAIN");
         if (e) f->persist_gain = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_EARLY");

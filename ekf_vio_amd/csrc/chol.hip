@@ -1165,7 +1165,7 @@ static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
 // deal gives a workgroup at most LA_MAX_TILES tiles and the flags fit; 0 = run the rounds as launches.
 // EKFVIO_SWEEP_LA_PERSIST=0 (diagnostic) keeps the launches.
 static int la_persist_grid(ekfvio_filter* f, int m_pad, int n_pad) {
-    static const bool on = getenv("EKFVIO_SWEEP_LA_PERSIST") ? atoi(getenv("EKFVIO_SWEEP_LA_PERSIST")) != 0 : false;  // (work in progress: opt-in)
+    const bool on = f->la_persist != 0;  // EKFVIO_SWEEP_LA_PERSIST=1 (opt-in: measured, not faster -- profiles/r04_persistent_split_sweep_experiment.txt)
     const int mb = m_pad / PB, rb = n_pad / PB + mb;
     if (!on || f->sweep_mode != 2 || mb < EKF_SWEEP_SPLIT_MB || live_handles_on(f->device) > 1 ||
         persist_flag_words(m_pad, n_pad) > f->sweep_sync_words) {

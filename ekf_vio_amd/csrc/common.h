@@ -105,6 +105,7 @@ struct ekfvio_filter {
     long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
     long long schur_sweeps = 0;       // sweeps enqueued with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1): ekfvio_test_sweep_counts
     long long sweep_recoveries = 0;   // updates run again with the per-step sweep behind an aborted persistent launch
+    int la_persist = 0;               // EKFVIO_SWEEP_LA_PERSIST: the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
     int la_persist_occupancy = -1;    // workgroups of chol_persist_la_kernel per compute unit (occupancy query, once)
     int sweep_spin_limit = 0;         // > 0: looks per wait of the persistent sweep (test hook ekfvio_test_sweep_fault); 0: SWEEP_SPIN_LIMIT
     int sweep_stall_wg = -1;          // fault injection: this workgroup of the persistent launch never raises its flag

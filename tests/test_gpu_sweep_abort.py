@@ -34,8 +34,10 @@ def _warm_state(N, steps=4):
     return sc, st, frames[steps:]
 
 
-@pytest.mark.parametrize("N,stall", [(256, 5), (256, 120), (128, 1)])
+@pytest.mark.parametrize("N,stall", [(256, 5), (256, 120), (128, 1), (544, 9)])
 def test_aborted_update_is_rerun_with_the_per_step_sweep_bit_for_bit(monkeypatch, N, stall):
+    """(N = 544: the split sweep's persistent form, an experiment behind EKFVIO_SWEEP_LA_PERSIST=1 -- chol_persist_la.inc; `stall` is then the row
+    worker that never publishes.)"""
     sc, st, frames = _warm_state(N)
     z, R, p = frames[0]
     # the answer: the same step with one launch per block step from the start
@@ -52,6 +54,8 @@ def test_aborted_update_is_rerun_with_the_per_step_sweep_bit_for_bit(monkeypatch
     assert ref.sweep_counts()["persistent"] == 0
     ref.close()
     monkeypatch.delenv("EKFVIO_SWEEP")
+    if N >= 512:
+        monkeypatch.setenv("EKFVIO_SWEEP_LA_PERSIST", "1")
 
     g = TightlyCoupledEKF(max_features=N)
     g.set_state(st)
