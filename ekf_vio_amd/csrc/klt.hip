@@ -931,8 +931,8 @@ static int ensure_frame_capacity(ekfvio_filter* f, int sw, int sh, int w, int h)
         if (f->staging) (void)hipFree(f->staging);
         if (f->h_image) (void)hipHostFree(f->h_image);
         f->staging = nullptr, f->h_image = nullptr, f->src_cap = 0;
-        HIPK(f, hipMalloc((void**)&f->staging, src));
-        HIPK(f, hipHostMalloc((void**)&f->h_image, src, hipHostMallocDefault));
+        HIPK(f, hipMalloc((void**)&f->staging, src + 16));  // (+16: the upload kernel moves whole 16-byte pieces)
+        HIPK(f, hipHostMalloc((void**)&f->h_image, src + 16, hipHostMallocMapped));
         f->src_cap = src;
     }
     if (w > fr.cap_w || h > fr.cap_h) {
@@ -959,8 +959,8 @@ int klt_alloc(ekfvio_filter* f) {
     HIPK(f, hipMalloc((void**)&f->klt_status, maxf));
     HIPK(f, hipMalloc((void**)&f->klt_cov_px, sizeof(float) * 4 * maxf));
     f->src_cap = (size_t)c.max_image_width * c.max_image_height;
-    HIPK(f, hipMalloc((void**)&f->staging, f->src_cap));
-    HIPK(f, hipHostMalloc((void**)&f->h_image, f->src_cap, hipHostMallocDefault));
+    HIPK(f, hipMalloc((void**)&f->staging, f->src_cap + 16));
+    HIPK(f, hipHostMalloc((void**)&f->h_image, f->src_cap + 16, hipHostMallocMapped));
     return EKFVIO_OK;
 }
 
@@ -1093,6 +1093,14 @@ int klt_track_device(ekfvio_filter* f) {
 // (Measured and dropped: the upload and the pyramid on a stream of their own beside process(dt), joined by an event in
 // front of the tracker.  The two cross-stream waits cost more than the 12 us of overlap they buy: 161 instead of 141 us
 // per frame at N = 64.)
+// The frame's trip to device memory: a kernel reading the pinned (mapped) host buffer, 16 bytes per lane.  The copy engine's
+// hipMemcpyAsync took 12.6 us for a 640 x 480 frame (rocprofv3), this ~6: the image loop gained 11 - 13 us per frame (same-box A/B,
+// N = 256 with outputs 198 -> 186 us, node defaults 136 -> 123 us).  EKFVIO_UPLOAD_KERNEL=0 brings the copy engine back.
+__global__ __launch_bounds__(256) void upload_frame_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 static int push_frame_check(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                             const float K[9]) {
     if (!f || !image || !K || width < 1 || height < 1 || stride < width) return EKFVIO_EINVAL;
@@ -1115,7 +1123,14 @@ static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t wi
         for (int y = 0; y < height; y++) memcpy(f->h_image + (size_t)y * width, image + (size_t)y * stride, width);
     }
     hipStream_t st = f->stream;
-    HIPK(f, hipMemcpyAsync(f->staging, f->h_image, (size_t)width * height, hipMemcpyHostToDevice, st));
+    static const int upload_kernel = getenv("EKFVIO_UPLOAD_KERNEL") ? atoi(getenv("EKFVIO_UPLOAD_KERNEL")) : 1;
+    if (upload_kernel) {
+        const int n16 = (int)(((size_t)width * height + 15) / 16);
+        hipLaunchKernelGGL(upload_frame_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(f->h_image),
+                           reinterpret_cast<uint4*>(f->staging), n16);
+    } else {
+        HIPK(f, hipMemcpyAsync(f->staging, f->h_image, (size_t)width * height, hipMemcpyHostToDevice, st));
+    }
     f->cur ^= 1;  // the former current frame becomes the previous one (frame_buffer depth 2)
     KltFrame& fr = f->frames[f->cur];
     for (int i = 0; i < 9; i++) fr.K[i] = K[i];
