@@ -395,6 +395,31 @@ __device__ inline float wave_sum_i32_as_float(int v) {
     const int lo = wave_sum_small_i32(v & 0xffff), hi = wave_sum_small_i32(v >> 16);
     return (float)((double)hi * 65536.0 + (double)lo);
 }
+// Two such sums at once (the Gauss-Newton step's b1, b2): the four 16-bit halves go through the butterfly in lockstep, so that every DPP
+// step finds three independent ones between itself and the step that reads its result -- one after the other, each step waits two
+// issue slots for its operand (the DPP read-after-write hazard): ~20 slots of the ~200 on the iteration's serial path.
+__device__ inline void wave_sum2_i32_as_float(int a, int b, float& fa, float& fb) {
+    int v0 = a & 0xffff, v1 = a >> 16, v2 = b & 0xffff, v3 = b >> 16;
+#define KLT_DPP4(ctrl, rmask, bound)                                        \
+    do {                                                                    \
+        const int t0 = __builtin_amdgcn_update_dpp(0, v0, ctrl, rmask, 0xf, bound); \
+        const int t1 = __builtin_amdgcn_update_dpp(0, v1, ctrl, rmask, 0xf, bound); \
+        const int t2 = __builtin_amdgcn_update_dpp(0, v2, ctrl, rmask, 0xf, bound); \
+        const int t3 = __builtin_amdgcn_update_dpp(0, v3, ctrl, rmask, 0xf, bound); \
+        v0 += t0, v1 += t1, v2 += t2, v3 += t3;                             \
+    } while (0)
+    KLT_DPP4(0xB1, 0xf, true);
+    KLT_DPP4(0x4E, 0xf, true);
+    KLT_DPP4(0x141, 0xf, true);
+    KLT_DPP4(0x140, 0xf, true);
+    KLT_DPP4(0x142, 0xa, false);
+    KLT_DPP4(0x143, 0xc, false);
+#undef KLT_DPP4
+    const int s0 = __builtin_amdgcn_readlane(v0, 63), s1 = __builtin_amdgcn_readlane(v1, 63);
+    const int s2 = __builtin_amdgcn_readlane(v2, 63), s3 = __builtin_amdgcn_readlane(v3, 63);
+    fa = (float)((double)s1 * 65536.0 + (double)s0);
+    fb = (float)((double)s3 * 65536.0 + (double)s2);
+}
 __device__ inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 // Copies `rows` rows of `nbytes` bytes starting at byte address src (row stride `pitch`, a multiple of 4) into LDS
@@ -641,7 +666,10 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, flo
                 }
             }
             itc++;
-            const float b1 = wave_sum_i32_as_float(pb1) * FLT_SCALE, b2 = wave_sum_i32_as_float(pb2) * FLT_SCALE;
+            float b1, b2;
+            wave_sum2_i32_as_float(pb1, pb2, b1, b2);
+            b1 *= FLT_SCALE;
+            b2 *= FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx;
