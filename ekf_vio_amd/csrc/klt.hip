@@ -1154,7 +1154,9 @@ static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t wi
     static const int upload_kernel = getenv("EKFVIO_UPLOAD_KERNEL") ? atoi(getenv("EKFVIO_UPLOAD_KERNEL")) : 1;
     if (upload_kernel) {
         const int n16 = (int)(((size_t)width * height + 15) / 16);
-        hipLaunchKernelGGL(upload_frame_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(f->h_image),
+        void* dsrc = nullptr;  // the device's address of the mapped buffer (the same pointer under unified addressing; asked for, not assumed)
+        HIPK(f, hipHostGetDevicePointer(&dsrc, f->h_image, 0));
+        hipLaunchKernelGGL(upload_frame_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(dsrc),
                            reinterpret_cast<uint4*>(f->staging), n16);
     } else {
         HIPK(f, hipMemcpyAsync(f->staging, f->h_image, (size_t)width * height, hipMemcpyHostToDevice, st));
