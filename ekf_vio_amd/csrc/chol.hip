@@ -1162,23 +1162,17 @@ static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
 }
 // The split sweep as one persistent launch (chol_persist_la.inc): the grid is every workgroup slot of the device (the occupancy
 // query's workgroups per compute unit x compute units: all must be resident, they wait for each other), admitted when the round-robin
-// deal gives a workgroup at most LA_MAX_TILES tiles and the flags fit; 0 = run the rounds as launches.
-// EKFVIO_SWEEP_LA_PERSIST=0 (diagnostic) keeps the launches.
+// deal gives a workgroup at most LA_MAX_TILES tiles and the flags fit; 0 = run the rounds as launches (the default).
 static int la_persist_grid(ekfvio_filter* f, int m_pad, int n_pad) {
     const bool on = f->la_persist != 0;  // EKFVIO_SWEEP_LA_PERSIST=1 (opt-in: measured, not faster -- profiles/r04_persistent_split_sweep_experiment.txt)
     const int mb = m_pad / PB, rb = n_pad / PB + mb;
     if (!on || f->sweep_mode != 2 || mb < EKF_SWEEP_SPLIT_MB || live_handles_on(f->device) > 1 ||
-        persist_flag_words(m_pad, n_pad) > f->sweep_sync_words) {
-        if (getenv("EKFVIO_DEBUG_LA"))
-            fprintf(stderr, "la_persist: off (on %d mode %d mb %d live %d words %zu / %zu)\n", (int)on, f->sweep_mode, mb, live_handles_on(f->device),
-                    persist_flag_words(m_pad, n_pad), f->sweep_sync_words);
+        persist_flag_words(m_pad, n_pad) > f->sweep_sync_words)
         return 0;
-    }
     if (f->la_persist_occupancy < 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(chol_persist_la_kernel), 256, 0) != hipSuccess) nb = 0;
         f->la_persist_occupancy = nb;
-        if (getenv("EKFVIO_DEBUG_LA")) fprintf(stderr, "la_persist: occupancy %d cus %d\n", nb, f->num_cus);
     }
     const int grid = f->la_persist_occupancy * f->num_cus;
     int tiles = 0;  // far owners' tiles: block columns >= 3
