@@ -121,6 +121,9 @@ __global__ void publish_status_kernel(const int* __restrict__ info, int* host_wo
     host_word[2] = extra ? *extra : 0;
     __hip_atomic_store(host_word + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+void launch_publish_status(ekfvio_filter* f, int seq) {
+    hipLaunchKernelGGL(publish_status_kernel, dim3(1), dim3(1), 0, f->stream, f->info, f->d_hinfo, seq, (const int*)nullptr);
+}
 int wait_status(ekfvio_filter* f, int* status, const int* extra_dev, int* extra_out) {
     const int seq = ++f->status_seq;
     hipLaunchKernelGGL(publish_status_kernel, dim3(1), dim3(1), 0, f->stream, f->info, f->d_hinfo, seq, extra_dev);
@@ -398,9 +401,9 @@ void sweep_abort_latch(ekfvio_filter* f) {
 // Waits for the stream and reads the status word.  An aborted update is enqueued again by `rerun` (null: the caller cannot,
 // e.g. a graph replay of many steps: EKFVIO_EABORTED) with the per-step sweep and awaited: fresh launches, same inputs,
 // and the state comes out as if the per-step sweep had run in the first place.
-int finish_update_rerun(ekfvio_filter* f, void (*rerun)(ekfvio_filter*, void*), void* ctx) {
+int finish_update_rerun(ekfvio_filter* f, void (*rerun)(ekfvio_filter*, void*), void* ctx, int published_seq) {
     int bad = 0;
-    int rc = wait_status(f, &bad);
+    int rc = published_seq ? poll_status(f, published_seq, &bad, nullptr) : wait_status(f, &bad);  // (published_seq: the caller's launches publish it)
     if (rc != EKFVIO_OK) return rc;
     if (bad) HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
     if (bad & 2) {
@@ -423,7 +426,7 @@ int finish_update_rerun(ekfvio_filter* f, void (*rerun)(ekfvio_filter*, void*), 
 
 extern "C" {
 
-static int finish_update(ekfvio_filter* f) { return finish_update_rerun(f, nullptr, nullptr); }
+static int finish_update(ekfvio_filter* f) { return finish_update_rerun(f, nullptr, nullptr, 0); }
 
 int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count) {
     if (!f || count != f->N) return EKFVIO_EINVAL;  // ROS_ASSERT :478
@@ -443,13 +446,22 @@ int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_
         memcpy(f->h_meas + 24 * cap, pass, count);
         HIPC(f, hipMemcpyAsync(f->d_meas, f->h_meas, 24 * cap + count, hipMemcpyHostToDevice, f->stream));
     }
+    // The status of an update -- a non-positive pivot, a sweep that gave up -- is final when the Cholesky sweep is: the status word goes to
+    // the host right behind the sweep, and the call returns while the two Joseph GEMMs are still running (everything the caller can do next
+    // is ordered behind them on the handle's stream, or synchronises).  A step-by-step caller then keeps the GPU fed: the next step's
+    // launches are in the queue before this step's last kernel ends (EKFVIO_EARLY_STATUS=0: publish behind the last kernel, as rounds 1-3).
+    static const bool early = getenv("EKFVIO_EARLY_STATUS") ? atoi(getenv("EKFVIO_EARLY_STATUS")) != 0 : true;
+    const int seq = next_status_seq(f);
+    f->publish_after_sweep_seq = early ? seq : 0;
     launch_update(f, m, dz, dR, dp);
+    if (f->publish_after_sweep_seq != 0 || !early) launch_publish_status(f, seq);  // (no sweep ran: nothing was published yet)
+    f->publish_after_sweep_seq = 0;
     HIPC(f, hipGetLastError());
     struct Ctx { int m; float *dz, *dR; uint8_t* dp; } ctx{m, dz, dR, dp};
     return finish_update_rerun(f, [](ekfvio_filter* g, void* c) {
         const Ctx* x = static_cast<const Ctx*>(c);
         launch_update(g, x->m, x->dz, x->dR, x->dp);  // the staged measurement is still in d_meas; the bookkeeping is idempotent
-    }, &ctx);
+    }, &ctx, seq);
 }
 
 int ekfvio_measurement_map(const ekfvio_filter* f, const uint8_t* measured, int32_t count, int32_t* idx, int32_t* rows) {

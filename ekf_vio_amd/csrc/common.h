@@ -105,6 +105,7 @@ struct ekfvio_filter {
     long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
     long long schur_sweeps = 0;       // sweeps enqueued with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1): ekfvio_test_sweep_counts
     long long sweep_recoveries = 0;   // updates run again with the per-step sweep behind an aborted persistent launch
+    int publish_after_sweep_seq = 0;  // ekfvio_update: launch_update publishes the status word with this sequence number right behind the sweep (0: not asked)
     int la_persist = 0;               // EKFVIO_SWEEP_LA_PERSIST: the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
     int la_persist_occupancy = -1;    // workgroups of chol_persist_la_kernel per compute unit (occupancy query, once)
     int sweep_spin_limit = 0;         // > 0: looks per wait of the persistent sweep (test hook ekfvio_test_sweep_fault); 0: SWEEP_SPIN_LIMIT
@@ -294,6 +295,7 @@ void fast_free(ekfvio_filter* f);
 int fast_ensure(ekfvio_filter* f, int w, int h);  // grows the detector's per-pixel buffers to a w x h level 0 (synchronises if it must)
 // Waits for everything on the handle's stream and returns the factorisation's status word through *status (api.hip).
 // extra_dev (may be null): one more device word delivered with it through *extra_out.
+void launch_publish_status(ekfvio_filter* f, int seq);  // the status word and `seq` to pinned host memory, stream-ordered (api.hip)
 int wait_status(ekfvio_filter* f, int* status, const int* extra_dev = nullptr, int* extra_out = nullptr);
 // the same in two halves, for a caller whose own (single-workgroup) kernel publishes the words itself
 int next_status_seq(ekfvio_filter* f);

@@ -986,6 +986,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         // reference's (I - K H) Sigma (I - K H)^T + K R K^T (:594-596), pruned (:625).  Its first workgroup finishes the
         // mean (:600-609).
         launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather, true);
+        if (f->publish_after_sweep_seq) launch_publish_status(f, f->publish_after_sweep_seq), f->publish_after_sweep_seq = 0;
         launch_joseph_g(f, m, m_pad, n_pad, m_on_device);
         ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad, 1);
         e2.abort = nullptr;
@@ -998,6 +999,8 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         // [A; Sigma H^T; I] -> [L; Y; L^-T], then K = (Sigma H^T) A^-1  (:577-580)
         if (fused_front) launch_persist_fused(f, m, m_pad, n_pad, m_on_device);
         else launch_chol_sweep(f, f->Saug, f->Laug, f->Linv, m_pad, n_pad, lda, fused_gather);
+        // (ekfvio_update: the update's status is final here -- the host gets it now and returns while the GEMMs below run)
+        if (f->publish_after_sweep_seq) launch_publish_status(f, f->publish_after_sweep_seq), f->publish_after_sweep_seq = 0;
         if (f->sweep_abort_word) {  // a persistent sweep ran: the update's last GEMM leaves its flags zero for the next one
             e2.zero_words = f->sweep_sync;
             e2.n_zero = persist_zero_words(m_pad, n_pad);

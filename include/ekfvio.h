@@ -114,7 +114,9 @@ int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense);
 /* updateWithFeaturePositions(z, R, pass) (TightlyCoupledEKF.cpp:475-628).  `count` must
  * equal the number of landmarks (reference ROS_ASSERT at :478).  Entries of z/R for
  * failed landmarks are ignored.  Returns EKFVIO_OK or EKFVIO_ENUMERIC (an aborted persistent sweep is
- * recovered inside the call, see EKFVIO_EABORTED). */
+ * recovered inside the call, see EKFVIO_EABORTED).  The call returns as soon as the update's status is known -- when the
+ * Cholesky sweep has ended; the covariance update behind it may still be running: every later call on this handle is ordered
+ * behind it or waits for it (ekfvio_synchronize waits explicitly). */
 int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count);
 
 /* formFeatureMeasurementMap (TightlyCoupledEKF.cpp:634-661): state index of the single 1.0
