@@ -40,7 +40,7 @@ SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_r
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
            "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
            "ekfvio_profile_update_gemms", "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps", "ekfvio_test_sweep_stamps", "ekfvio_test_persistent_sweeps",
-           "ekfvio_test_sweep_counts", "ekfvio_test_sweep_fault",
+           "ekfvio_test_sweep_counts", "ekfvio_test_early_output_frames", "ekfvio_test_sweep_fault",
            "ekfvio_test_cholesky_solve", "ekfvio_test_klt_padded_level"]
 
 _lib = None
@@ -92,6 +92,7 @@ def load(build_if_missing=True):
         "ekfvio_test_sweep_stamps": [vp, C.c_int, C.POINTER(C.c_int64)],
         "ekfvio_test_persistent_sweeps": [vp, C.POINTER(C.c_int64)],
         "ekfvio_test_sweep_counts": [vp, C.POINTER(C.c_int64)], "ekfvio_test_sweep_fault": [vp, i32, i32],
+        "ekfvio_test_early_output_frames": [vp, C.POINTER(C.c_int64)],
         "ekfvio_test_gemm_bench": [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():

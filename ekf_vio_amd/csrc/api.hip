@@ -240,6 +240,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->fuse_sweep = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_OVERSUB");
         if (e) f->persist_oversub = atoi(e);
+        e = getenv("EKFVIO_EARLY_OUTPUTS");  // tuning knob: 0 = a frame's outputs behind its last kernel (rounds 1-3)
+        if (e) f->early_outputs = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_SWEEP_LA_PERSIST");  // experiment: 1 = the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
         if (e) f->la_persist = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_GAIN");
@@ -984,6 +986,12 @@ int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t* stamps /* [1
 int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count) {
     if (!f || !count) return EKFVIO_EINVAL;
     *count = f->persistent_sweeps;
+    return EKFVIO_OK;
+}
+
+int ekfvio_test_early_output_frames(ekfvio_filter* f, int64_t* count) {
+    if (!f || !count) return EKFVIO_EINVAL;
+    *count = f->early_output_frames;
     return EKFVIO_OK;
 }
 

@@ -105,6 +105,10 @@ struct ekfvio_filter {
     long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
     long long schur_sweeps = 0;       // sweeps enqueued with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1): ekfvio_test_sweep_counts
     long long sweep_recoveries = 0;   // updates run again with the per-step sweep behind an aborted persistent launch
+    int early_outputs = 1;            // EKFVIO_EARLY_OUTPUTS: a frame's outputs and status go out between the update's two Joseph GEMMs (klt.hip)
+    void (*between_joseph)(ekfvio_filter*) = nullptr;  // ekfvio_step_image: called by launch_update between the update's two Joseph GEMMs (the frame's outputs)
+    int between_joseph_seq = 0;       // ... and the status sequence number its launch publishes (0: not called)
+    long long early_output_frames = 0;  // frames whose outputs went out that way (test hook)
     int publish_after_sweep_seq = 0;  // ekfvio_update: launch_update publishes the status word with this sequence number right behind the sweep (0: not asked)
     int la_persist = 0;               // EKFVIO_SWEEP_LA_PERSIST: the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
     int la_persist_occupancy = -1;    // workgroups of chol_persist_la_kernel per compute unit (occupancy query, once)

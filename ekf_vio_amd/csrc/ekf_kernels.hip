@@ -1020,6 +1020,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             //   Sigma' = T + G*K^T, pruned (:594-596, :625); workgroup (0,0) finishes the mean
             ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)(n + 1) * m_pad + 2.0 * n * (double)n * m_pad, 2);
             launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
+            if (f->between_joseph) f->between_joseph(f);  // (ekfvio_step_image: the frame's outputs, from mu and K y in column n of P)
             launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
         } else {
             // The symmetric flow (round 4 experiment, EKFVIO_JOSEPH_SYM=1; measured and not adopted, see common.h and DESIGN.md).

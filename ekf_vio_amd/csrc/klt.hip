@@ -756,12 +756,29 @@ __global__ void points_kernel(const float* __restrict__ mu, int N, const uint8_t
 // wait each (the node's loop with outputs: 164 -> 140 us per frame at the node's defaults).  One workgroup; the number of
 // landmarks is N_old plus what the replenishment just added (added_dev, may be null).
 // Layout of out: base_mu[22], xyz[3 N], intensity[N].
+// Pcol != null (round 4): launched BETWEEN the update's two Joseph GEMMs.  The mean update mu += K y, quaternion renormalised, is the
+// second GEMM's (gemm.hip, mode 2, :600-609) from K y in column n of P, which the first one has just left there: the same sums are
+// formed here (into LDS, mu itself is not touched), so the frame's outputs and status reach the host while the second GEMM still runs
+// -- the host's next frame (copying the image, ~15 us) starts that much earlier.  Same values, same bits as behind the update.
 __global__ __launch_bounds__(256) void frame_outputs_kernel(const float* __restrict__ mu, int N_old, const int* __restrict__ added_dev,
                                                             const uint8_t* __restrict__ img, int pitch, int w, int h, float fx, float fy,
                                                             float cx, float cy, float* __restrict__ out, const int* __restrict__ info,
-                                                            int* host_word, int seq) {
+                                                            int* host_word, int seq, const float* __restrict__ Pcol) {
+    extern __shared__ float s_mu[];  // Pcol: the updated mean, EKF_BASE + 3 N floats
     const int added = added_dev ? *added_dev : 0;
     const int N = N_old + added;
+    if (Pcol) {
+        const int n = EKF_BASE + 3 * N;
+        for (int e = threadIdx.x; e < n; e += 256) s_mu[e] = mu[e] + Pcol[e];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float q0 = s_mu[3], q1 = s_mu[4], q2 = s_mu[5], q3 = s_mu[6];
+            const float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+            s_mu[3] = q0 / qn, s_mu[4] = q1 / qn, s_mu[5] = q2 / qn, s_mu[6] = q3 / qn;
+        }
+        __syncthreads();
+        mu = s_mu;
+    }
     if (threadIdx.x < EKF_BASE) out[threadIdx.x] = mu[threadIdx.x];
     float* xyz = out + EKF_BASE;
     float* inten = xyz + 3 * (size_t)N;
@@ -1360,12 +1377,33 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         return EKFVIO_OK;
     }
     int status = EKFVIO_OK;
+    int early_seq = 0;
     if (f->N > 0) {  // "run update if we have enough features" (EKFVIO.cpp:166)
         rc = klt_track_device(f);
         if (rc != EKFVIO_OK) return fail(rc);
         // the pass flags stay on the device: the update is launched for m = 2N measurement rows and its kernels take
         // the true count from the bookkeeping (rows beyond it are identity padding, exact zeros in every product)
+        // A frame that adds no landmarks publishes its outputs and its status BETWEEN the update's two Joseph GEMMs (frame_outputs_kernel,
+        // Pcol): launch_update calls back there.  (With landmarks to add the selection reads the updated mean and the outputs carry the count:
+        // behind the update, as before.  EKFVIO_EARLY_OUTPUTS=0: always behind.)
+        if (f->early_outputs && f->frame_outputs && !(f->cfg.replenish && f->N < f->cfg.max_features)) {
+            f->between_joseph = [](ekfvio_filter* g) {
+                const KltFrame& fr = g->frames[g->cur];
+                const int pitch = level_pitch(fr.w[0]);
+                float fx, fy, cx, cy;
+                intrinsics(g, fr.K, &fx, &fy, &cx, &cy);
+                g->between_joseph_seq = next_status_seq(g);
+                hipLaunchKernelGGL(frame_outputs_kernel, dim3(1), dim3(256), sizeof(float) * (size_t)g->n, g->stream, g->mu, g->N, (const int*)nullptr,
+                                   fr.img[0] + (size_t)KLT_BORDER * pitch + KLT_BORDER, pitch, fr.w[0], fr.h[0], fx, fy, cx, cy, g->d_out, g->info,
+                                   g->d_hinfo, g->between_joseph_seq, (const float*)(g->P + (size_t)g->n * g->ldp));
+            };
+            f->between_joseph_seq = 0;
+        }
         launch_update(f, 0, f->zmeas, f->Rmeas, f->pass, nullptr, 0, false, true);
+        f->between_joseph = nullptr;
+        early_seq = f->between_joseph_seq;  // 0: the hook was not reached (no measurement, another flow of the update)
+        if (early_seq) f->early_output_frames++;
+        f->between_joseph_seq = 0;
     }
     if (hipGetLastError() != hipSuccess) {
         f->last_error = "launch failed in ekfvio_step_image";
@@ -1390,11 +1428,15 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         const int pitch = level_pitch(fr.w[0]);
         float fx, fy, cx, cy;
         intrinsics(f, fr.K, &fx, &fy, &cx, &cy);
-        const int seq = next_status_seq(f);
-        hipLaunchKernelGGL(frame_outputs_kernel, dim3(1), dim3(256), 0, f->stream, f->mu, f->N, replenishing ? f->fast_counts + 1 : nullptr,
-                           fr.img[0] + (size_t)KLT_BORDER * pitch + KLT_BORDER, pitch, fr.w[0], fr.h[0], fx, fy, cx, cy, f->d_out, f->info,
-                           f->d_hinfo, seq);
-        rc = poll_status(f, seq, &bad, &added);
+        if (early_seq) {  // (the outputs went out between the Joseph GEMMs: launch_update's hook)
+            rc = poll_status(f, early_seq, &bad, &added);
+        } else {
+            const int seq = next_status_seq(f);
+            hipLaunchKernelGGL(frame_outputs_kernel, dim3(1), dim3(256), 0, f->stream, f->mu, f->N, replenishing ? f->fast_counts + 1 : nullptr,
+                               fr.img[0] + (size_t)KLT_BORDER * pitch + KLT_BORDER, pitch, fr.w[0], fr.h[0], fx, fy, cx, cy, f->d_out, f->info,
+                               f->d_hinfo, seq, (const float*)nullptr);
+            rc = poll_status(f, seq, &bad, &added);
+        }
     }
     if (rc != EKFVIO_OK) return rc;
     f->out_fresh = f->frame_outputs != 0;

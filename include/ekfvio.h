@@ -260,6 +260,8 @@ int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count);
 /* Diagnostic: counts[0] persistent sweeps, [1] sweeps with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1), [2] updates run
    again behind an aborted persistent sweep, [3] the handle's sweep mode now (2: persistent where it applies, 0: per-step). */
 int ekfvio_test_sweep_counts(ekfvio_filter* f, int64_t counts[4]);
+/* Diagnostic: frames of ekfvio_step_image whose outputs and status were published between the update's two Joseph GEMMs. */
+int ekfvio_test_early_output_frames(ekfvio_filter* f, int64_t* count);
 /* Fault injection for the persistent sweep: at most `spin_limit` looks per wait (0: the production limit), and workgroup
    `stall_workgroup` of the launch never raises its tile's flag (-1: none), so every wait behind it runs out. */
 int ekfvio_test_sweep_fault(ekfvio_filter* f, int32_t spin_limit, int32_t stall_workgroup);

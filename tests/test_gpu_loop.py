@@ -185,6 +185,41 @@ def test_teacher_forced_image_loop_with_replenishment():
     v.tc_ekf.close()
 
 
+def test_frame_outputs_published_between_the_joseph_gemms_are_the_updated_state(monkeypatch):
+    """A frame that adds no landmarks publishes its outputs and its status between the update's two Joseph GEMMs (round 4: the host's
+    next frame starts while the second GEMM runs): frame_outputs_kernel forms mu + K y (quaternion renormalised) itself, from K y in column n
+    of P, where the second GEMM's first workgroup will find it.  The outputs must be the updated state's own numbers, and the whole
+    sequence must agree bit for bit with EKFVIO_EARLY_OUTPUTS=0 (outputs behind the last kernel)."""
+    import ctypes as C
+    base = grey()
+    seq = translated_sequence(base, 14, dx=-1.4, dy=-0.45)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EKFVIO_EARLY_OUTPUTS", mode)
+        v = EKFVIO(max_features=48, replenish=1)  # full after the first frame: later frames add nothing
+        rows = []
+        for i, img in enumerate(seq):
+            v.addFrame(7.0 + i / 30.0, img, K)
+            od = v.odometry()
+            xyz, inten = v.points()
+            sg = v.tc_ekf.get_state()
+            assert np.array_equal(od["position"], sg["base_mu"][0:3]) and np.array_equal(od["orientation_wxyz"], sg["base_mu"][3:7]), (mode, i)
+            zinv = (1.0 / sg["feat_mu"][:, 2].astype(np.float64)).astype(np.float32)
+            assert np.array_equal(xyz, np.stack([sg["feat_mu"][:, 0] * zinv, sg["feat_mu"][:, 1] * zinv, zinv], axis=1)), (mode, i)
+            rows.append((od["position"].copy(), od["orientation_wxyz"].copy(), xyz.copy(), inten.copy(), sg["Sigma"].copy()))
+        n_early = C.c_int64(0)
+        assert v.tc_ekf.lib.ekfvio_test_early_output_frames(v.tc_ekf.h, C.byref(n_early)) == 0
+        if mode == "1":
+            assert n_early.value >= 8, n_early.value  # (frames with all 48 landmarks alive; a lost landmark makes the next frame replenish)
+        else:
+            assert n_early.value == 0
+        runs[mode] = rows
+        v.tc_ekf.close()
+    for i, (a, b) in enumerate(zip(runs["1"], runs["0"])):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), i
+
+
 @pytest.mark.parametrize("thr,dist,expect_n", [(50, 30, 90), (20, 12, 250)])
 def test_free_running_loop_loses_what_the_oracle_loop_loses(thr, dist, expect_n):
     """46 frames of a 1.4 px / frame translation, capacity 256.  With the node's default
