@@ -1386,7 +1386,8 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         // A frame that adds no landmarks publishes its outputs and its status BETWEEN the update's two Joseph GEMMs (frame_outputs_kernel,
         // Pcol): launch_update calls back there.  (With landmarks to add the selection reads the updated mean and the outputs carry the count:
         // behind the update, as before.  EKFVIO_EARLY_OUTPUTS=0: always behind.)
-        if (f->early_outputs && f->frame_outputs && !(f->cfg.replenish && f->N < f->cfg.max_features)) {
+        if (f->early_outputs && f->frame_outputs && !(f->cfg.replenish && f->N < f->cfg.max_features) &&
+            sizeof(float) * (size_t)f->n <= 48 * 1024) {  // (the updated mean is formed in LDS)
             f->between_joseph = [](ekfvio_filter* g) {
                 const KltFrame& fr = g->frames[g->cur];
                 const int pitch = level_pitch(fr.w[0]);
