@@ -575,6 +575,7 @@ def main():
                 extra["other_sizes"] = {"error": repr(ex)}
             try:
                 extra["full_loop"] = {"n64": full_loop(64, local), "n256": full_loop(256, local),
+                                      "n256_with_outputs": full_loop(256, local, outputs=True),
                                       "node_defaults_n100_scale4": full_loop(100, local, node_defaults=True),
                                       "node_defaults_with_outputs": full_loop(100, local, node_defaults=True, outputs=True)}
                 extra["klt"] = extra["full_loop"]["n256"].pop("klt")
