@@ -207,6 +207,13 @@ def test_frame_outputs_published_between_the_joseph_gemms_are_the_updated_state(
             zinv = (1.0 / sg["feat_mu"][:, 2].astype(np.float64)).astype(np.float32)
             assert np.array_equal(xyz, np.stack([sg["feat_mu"][:, 0] * zinv, sg["feat_mu"][:, 1] * zinv, zinv], axis=1)), (mode, i)
             rows.append((od["position"].copy(), od["orientation_wxyz"].copy(), xyz.copy(), inten.copy(), sg["Sigma"].copy()))
+        # (the C entry point the Python mirror no longer goes through: the same four slices of the base state)
+        p3, q4, l3, a3 = (np.zeros(k, np.float32) for k in (3, 4, 3, 3))
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        assert v.tc_ekf.lib.ekfvio_get_odometry(v.tc_ekf.h, fp(p3), fp(q4), fp(l3), fp(a3)) == 0
+        od = v.odometry()
+        assert np.array_equal(p3, od["position"]) and np.array_equal(q4, od["orientation_wxyz"])
+        assert np.array_equal(l3, od["linear"]) and np.array_equal(a3, od["angular"])
         n_early = C.c_int64(0)
         assert v.tc_ekf.lib.ekfvio_test_early_output_frames(v.tc_ekf.h, C.byref(n_early)) == 0
         if mode == "1":
