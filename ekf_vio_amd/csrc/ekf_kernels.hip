@@ -34,18 +34,29 @@ __device__ inline V3 qrot(const Q4& q, const V3& v) {
     V3 c = cross3(qv, uv);
     return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
 }
+// The reference is an x86-64 build of Eigen with its vectorisation on (CMakeLists.txt:15 overwrites the -msse* flags of
+// :9, so plain x86-64: SSE2, no SSE3 / FMA): the three functions below follow that build's rounding order, as
+// oracle/ekf_oracle.hpp does by default (Config::eigen_sse_quat; the other orders are variants the CPU tests compare).
+// Vector4f::squaredNorm() over the coefficients (x,y,z,w): a packet of squares reduced by SSE2 predux, (c0+c2)+(c1+c3)
+__device__ inline float squared_norm4(const Q4& q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
 __device__ inline Q4 qinverse(const Q4& q) {
-    float n2 = (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+    float n2 = squared_norm4(q);
     if (n2 > 0.f) return {q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
     return {0.f, 0.f, 0.f, 0.f};
 }
 __device__ inline Q4 qnormalized(const Q4& q) {
-    float n = sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+    float n = sqrtf(squared_norm4(q));
     return {q.w / n, q.x / n, q.y / n, q.z / n};
 }
+// Geometry_SSE.h quat_product<Architecture::SSE, ., ., float>:
+// (a * b.wwww - a.zxyx * b.yzxx) + (+,+,+,-)(a.yzxz * b.zxyz + a.wwwy * b.xyzy)
 __device__ inline Q4 qmul(const Q4& a, const Q4& b) {
-    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+    Q4 r;
+    r.x = (a.x * b.w - a.z * b.y) + (a.y * b.z + a.w * b.x);
+    r.y = (a.y * b.w - a.x * b.z) + (a.z * b.x + a.w * b.y);
+    r.z = (a.z * b.w - a.y * b.x) + (a.x * b.y + a.w * b.z);
+    r.w = (a.w * b.w - a.x * b.x) + (-(a.z * b.z + a.y * b.y));
+    return r;
 }
 __device__ inline float norm3(const V3& v) { return sqrtf(v.x * v.x + (v.y * v.y + v.z * v.z)); }
 

@@ -45,7 +45,29 @@ struct Config {
     double default_point_depth_variance = 100.0;      // Params.h:84
     double default_point_homogenous_variance = 1e-5;  // Params.h:86
     int emulate_static_cache = 1;  // TightlyCoupledEKF.cpp:400-403 function-static dq_inv
+    // --- which Eigen build the restatement follows (the reference pins neither Eigen's version nor its
+    // vectorisation; CMakeLists.txt:9 asks for -msse..-mssse3 but :15 overwrites CMAKE_CXX_FLAGS, so a Release
+    // build is plain x86-64 = SSE2, EIGEN_VECTORIZE_SSE defined, no SSE3 / FMA).  tests/test_oracle_variants_cpu.py
+    // measures how far the variants are apart.
+    // eigen_sse_quat = 1 (default): Geometry/arch/Geometry_SSE.h quat_product<Architecture::SSE, ., ., float> for
+    //   `quat *= dq` (:362), and the 4-float squaredNorm() inside dq.inverse() (:357) / dq.normalize() (:347, :432)
+    //   reduced by SSE2 predux: (c0+c2)+(c1+c3) over the coefficient order (x,y,z,w).  0 = Eigen's generic
+    //   product and the unrolled scalar reduction (c0+c1)+(c2+c3) (EIGEN_DONT_VECTORIZE / a non-x86 build).
+    int eigen_sse_quat = 1;
+    // trig_float = 1: `sin(theta/2)` / `cos(theta/2)` (:352-354, :437-439) resolve to the float overloads
+    //   (a <math.h> that pulls std::sin(float) into the global namespace, GCC >= 6 with the C header included
+    //   directly); 0 (default): ::sin(double) on the promoted argument, narrowed on assignment (GCC 5, <cmath> only).
+    int trig_float = 0;
+    // div_reciprocal = 1: `vector /= scalar` (:198, :214, :243, :277, :293, :309 and normalize()) multiplies by
+    //   Scalar(1)/scalar (Eigen <= 3.2.x SelfCwiseBinaryOp.h); 0 (default): a true division (Eigen >= 3.2.90).
+    int div_reciprocal = 0;
 };
+
+// the three arithmetic choices above, passed down to the free functions
+struct Arith {
+    int sse_quat = 1, trig_float = 0, div_reciprocal = 0;
+};
+static inline Arith arith_of(const Config& c) { return Arith{c.eigen_sse_quat, c.trig_float, c.div_reciprocal}; }
 
 template <class T>
 struct Quat {
@@ -72,27 +94,63 @@ static inline Vec3<T> rotate(const Quat<T>& q, const Vec3<T>& v) {
     return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
 }
 
-// Eigen QuaternionBase::inverse(): conjugate().coeffs() / squaredNorm()
+// Vector4f::squaredNorm() of the coefficients (x,y,z,w).  Vectorised (SSE2, no SSE3): one packet of squares,
+// predux = a + movehl(a) then lane 0 + lane 1 = (x2+z2)+(y2+w2).  Scalar: redux_novec_unroller halves the range,
+// (x2+y2)+(z2+w2).
 template <class T>
-static inline Quat<T> inverse(const Quat<T>& q) {
-    T n2 = (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+static inline T squared_norm4(const Quat<T>& q, const Arith& ar) {
+    if (ar.sse_quat) return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w);
+    return (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+}
+
+// Eigen QuaternionBase::inverse(): conjugate().coeffs() / squaredNorm()  (operator/ is a true division in every
+// Eigen 3.x; the SSE conjugate is a sign-bit xor, exact)
+template <class T>
+static inline Quat<T> inverse(const Quat<T>& q, const Arith& ar) {
+    T n2 = squared_norm4(q, ar);
     if (n2 > T(0)) return {q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
     return {T(0), T(0), T(0), T(0)};
 }
 
+// coeffs().normalize(): `*this /= norm()` (3.2) / `z = squaredNorm(); if (z > 0) *this /= sqrt(z)` (3.3)
 template <class T>
-static inline Quat<T> normalized(const Quat<T>& q) {
-    T n = std::sqrt((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+static inline Quat<T> normalized(const Quat<T>& q, const Arith& ar) {
+    T n = std::sqrt(squared_norm4(q, ar));
+    if (ar.div_reciprocal) {
+        T r = T(1) / n;
+        return {q.w * r, q.x * r, q.y * r, q.z * r};
+    }
     return {q.w / n, q.x / n, q.y / n, q.z / n};
 }
 
-// Eigen generic quat_product (Hamilton)
+// a * b.  sse_quat: Geometry_SSE.h (3.2 and 3.3 round identically: 3.2 flips the sign of the two w products before
+// adding them, 3.3 after):  res = (a * b.wwww - a.zxyx * b.yzxx) + (+,+,+,-)(a.yzxz * b.zxyz + a.wwwy * b.xyzy).
+// Otherwise Eigen's generic quat_product (Hamilton, left to right).
 template <class T>
-static inline Quat<T> qmul(const Quat<T>& a, const Quat<T>& b) {
+static inline Quat<T> qmul(const Quat<T>& a, const Quat<T>& b, const Arith& ar) {
+    if (ar.sse_quat) {
+        Quat<T> r;
+        r.x = (a.x * b.w - a.z * b.y) + (a.y * b.z + a.w * b.x);
+        r.y = (a.y * b.w - a.x * b.z) + (a.z * b.x + a.w * b.y);
+        r.z = (a.z * b.w - a.y * b.x) + (a.x * b.y + a.w * b.z);
+        r.w = (a.w * b.w - a.x * b.x) + (-(a.z * b.z + a.y * b.y));
+        return r;
+    }
     return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
             a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
             a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+
+static inline float sin_as(float x, int trig_float) { return trig_float ? sinf(x) : (float)std::sin((double)x); }
+static inline float cos_as(float x, int trig_float) { return trig_float ? cosf(x) : (float)std::cos((double)x); }
+static inline double sin_as(double x, int) { return std::sin(x); }
+static inline double cos_as(double x, int) { return std::cos(x); }
+
+// `v /= s` on an Eigen vector (the finite differences' `/= 2*DELTA_SHIFT`)
+template <class T>
+static inline T vec_div(T x, T s, const Arith& ar) {
+    return ar.div_reciprocal ? x * (T(1) / s) : x / s;
 }
 
 // Vector3f::norm(): Eigen's unrolled reduction for 3 coefficients is c0 + (c1 + c2)
@@ -112,17 +170,17 @@ static inline Vec3<T> translation(const Vec3<T>& vel, const Vec3<T>& acc, T dt) 
 // dq = exp(omega*dt) as the reference builds it (TightlyCoupledEKF.cpp:340-355); sign=-1
 // gives the convolveFeature variant (:427-440) which negates the vector part.
 template <class T>
-static inline Quat<T> delta_quat(const Vec3<T>& omega, T dt, T sign) {
+static inline Quat<T> delta_quat(const Vec3<T>& omega, T dt, T sign, const Arith& ar) {
     T on = norm3(omega);
     if (on < (T)1e-10) {
         Quat<T> q{T(1), sign * omega.x * dt, sign * omega.y * dt, sign * omega.z * dt};
-        return normalized(q);
+        return normalized(q, ar);
     }
     T theta = dt * on;
     Vec3<T> oh{omega.x / on, omega.y / on, omega.z / on};
     T half = theta / 2;
-    T st2 = (T)std::sin((double)half);
-    T ct2 = (T)std::cos((double)half);
+    T st2 = sin_as(half, ar.trig_float);
+    T ct2 = cos_as(half, ar.trig_float);
     return {ct2, sign * oh.x * st2, sign * oh.y * st2, sign * oh.z * st2};
 }
 
@@ -194,13 +252,14 @@ struct Filter {
         Vec3<T> d = rotate(quat, translation(vel, accel, dt));
         pos = {pos.x + d.x, pos.y + d.y, pos.z + d.z};
 
-        Quat<T> dq = delta_quat(omega, dt, T(1));
-        Quat<T> dq_inv = inverse(dq);
+        const Arith ar = arith_of(cfg);
+        Quat<T> dq = delta_quat(omega, dt, T(1), ar);
+        Quat<T> dq_inv = inverse(dq, ar);
 
         Vec3<T> va{vel.x + dt * accel.x, vel.y + dt * accel.y, vel.z + dt * accel.z};
         vel = rotate(dq_inv, va);
         accel = rotate(dq_inv, accel);
-        quat = qmul(quat, dq);
+        quat = qmul(quat, dq, ar);
 
         out[0] = pos.x; out[1] = pos.y; out[2] = pos.z;
         out[3] = quat.w; out[4] = quat.x; out[5] = quat.y; out[6] = quat.z;
@@ -223,12 +282,12 @@ struct Filter {
         Quat<T> dq_inv;
         if (cfg.emulate_static_cache) {
             if (cache_om[0] != base[10] || cache_om[1] != base[11] || cache_om[2] != base[12]) {
-                cache_dq_inv = delta_quat(Vec3<T>{base[10], base[11], base[12]}, dt, T(-1));
+                cache_dq_inv = delta_quat(Vec3<T>{base[10], base[11], base[12]}, dt, T(-1), arith_of(cfg));
                 cache_om[0] = base[10]; cache_om[1] = base[11]; cache_om[2] = base[12];
             }
             dq_inv = cache_dq_inv;
         } else {
-            dq_inv = delta_quat(Vec3<T>{base[10], base[11], base[12]}, dt, T(-1));
+            dq_inv = delta_quat(Vec3<T>{base[10], base[11], base[12]}, dt, T(-1), arith_of(cfg));
         }
 
         Vec3<T> a = rotate(dq_inv, p);
@@ -262,6 +321,7 @@ struct Filter {
     // TightlyCoupledEKF.cpp:176-325; F dense column-major n x n (zero elsewhere)
     void linearize(T dt, std::vector<T>& F) {
         const int N = num_features();
+        const Arith ar = arith_of(cfg);
         F.assign((size_t)n * n, T(0));
         auto Fat = [&](int i, int j) -> T& { return F[(size_t)j * n + i]; };
         T test_mu[BASE];
@@ -275,14 +335,14 @@ struct Filter {
                 test_mu[j] = minus_2delta(test_mu[j]);
                 convolve_base_state(test_mu, dt, lo);
                 test_mu[j] = base_mu[j];
-                for (int i = 0; i < BASE; i++) Fat(i, j) = (hi[i] - lo[i]) / two_delta();
+                for (int i = 0; i < BASE; i++) Fat(i, j) = vec_div((T)(hi[i] - lo[i]), two_delta(), ar);
             } else if (j <= 15) {
                 test_mu[j] = plus_delta(test_mu[j]);
                 convolve_base_state(test_mu, dt, hi);
                 test_mu[j] = minus_2delta(test_mu[j]);
                 convolve_base_state(test_mu, dt, lo);
                 test_mu[j] = base_mu[j];
-                for (int i = 0; i < BASE; i++) Fat(i, j) = (hi[i] - lo[i]) / two_delta();
+                for (int i = 0; i < BASE; i++) Fat(i, j) = vec_div((T)(hi[i] - lo[i]), two_delta(), ar);
 
                 test_mu[j] = plus_delta(test_mu[j]);
                 for (int f = 0; f < N; f++) convolve_feature(test_mu, &feat_mu[3 * f], dt, &fd[3 * f]);
@@ -292,7 +352,7 @@ struct Filter {
                     fd[3 * f] -= tmp[0]; fd[3 * f + 1] -= tmp[1]; fd[3 * f + 2] -= tmp[2];
                 }
                 test_mu[j] = base_mu[j];
-                for (int r = 0; r < 3 * N; r++) Fat(BASE + r, j) = fd[r] / two_delta();
+                for (int r = 0; r < 3 * N; r++) Fat(BASE + r, j) = vec_div(fd[r], two_delta(), ar);
             } else {
                 Fat(j, j) = T(1);
             }
@@ -309,7 +369,7 @@ struct Filter {
                 test[c] = minus_2delta(test[c]);
                 convolve_feature(base_mu, test, dt, dlo);
                 test[c] = basef[c];
-                for (int r = 0; r < 3; r++) Fat(row + r, col) = (dhi[r] - dlo[r]) / two_delta();
+                for (int r = 0; r < 3; r++) Fat(row + r, col) = vec_div((T)(dhi[r] - dlo[r]), two_delta(), ar);
                 col++;
             }
         }

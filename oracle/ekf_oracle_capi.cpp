@@ -19,6 +19,13 @@ using oracle::BASE;
         return new oracle::Filter<T>(c);                                                                   \
     }                                                                                                      \
     extern "C" void P##_destroy(void* h) { delete (oracle::Filter<T>*)h; }                                 \
+    /* which Eigen build the restatement follows (ekf_oracle.hpp Config); -1 leaves a switch as it is */   \
+    extern "C" void P##_set_variant(void* h, int sse_quat, int trig_float, int div_reciprocal) {           \
+        auto* f = (oracle::Filter<T>*)h;                                                                   \
+        if (sse_quat >= 0) f->cfg.eigen_sse_quat = sse_quat;                                               \
+        if (trig_float >= 0) f->cfg.trig_float = trig_float;                                               \
+        if (div_reciprocal >= 0) f->cfg.div_reciprocal = div_reciprocal;                                   \
+    }                                                                                                      \
     extern "C" int P##_num_features(void* h) { return ((oracle::Filter<T>*)h)->num_features(); }           \
     extern "C" int P##_dim(void* h) { return ((oracle::Filter<T>*)h)->n; }                                 \
     extern "C" void P##_add_features(void* h, const T* uv, int k) {                                        \

@@ -43,6 +43,7 @@ def _declare(lib):
         g("create").restype = vp
         g("create").argtypes = [C.c_double, C.c_double, C.c_double, i32]
         g("destroy").argtypes = [vp]
+        g("set_variant").argtypes = [vp, i32, i32, i32]
         g("num_features").argtypes = [vp]
         g("dim").argtypes = [vp]
         g("add_features").argtypes = [vp, tp, i32]
@@ -97,15 +98,24 @@ class OracleFilter:
     """CPU restatement of TightlyCoupledEKF.  dtype=np.float32 is the reference
     precision; np.float64 is the yardstick."""
 
-    def __init__(self, dtype=np.float32, depth=0.5, depth_var=100.0, homog_var=1e-5, emulate_static_cache=True):
+    def __init__(self, dtype=np.float32, depth=0.5, depth_var=100.0, homog_var=1e-5, emulate_static_cache=True,
+                 eigen_sse_quat=None, trig_float=None, div_reciprocal=None):
         self.lib = oracle_lib()
         self.dtype = np.dtype(dtype)
         self.pre = "orc32" if self.dtype == np.float32 else "orc64"
         self.ct = C.c_float if self.dtype == np.float32 else C.c_double
         self.h = C.c_void_p(self._f("create")(depth, depth_var, homog_var, int(bool(emulate_static_cache))))
+        self.set_variant(eigen_sse_quat, trig_float, div_reciprocal)
 
     def _f(self, name):
         return getattr(self.lib, self.pre + "_" + name)
+
+    def set_variant(self, eigen_sse_quat=None, trig_float=None, div_reciprocal=None):
+        """Which x86-64 Eigen build the restatement follows (ekf_oracle.hpp Config): SSE2 quaternion product and
+        reduction order (default on), float sin/cos (default off), `/=` as a reciprocal multiply (default off).
+        None leaves a switch unchanged."""
+        enc = lambda v: -1 if v is None else int(bool(v))
+        self._f("set_variant")(self.h, enc(eigen_sse_quat), enc(trig_float), enc(div_reciprocal))
 
     def close(self):
         if self.h:
