@@ -313,7 +313,7 @@ def concurrent_sequences(n_landmarks, device, sequences, steps, dt_warm=10):
             "per_sequence_steps_per_s": steps / el, "states_finite": ok}
 
 
-def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="structured", depth_var=100.0):
+def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="structured", depth_var=100.0, with_roofline=False):
     """steps/s of a device-resident run at another size or predict mode (an extra, never `value`): same procedure as the
     headline (graphs prepared first, `steps` steps between two synchronises), median of five readings."""
     from ekf_vio_amd import TightlyCoupledEKF, capi
@@ -341,6 +341,34 @@ def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="struc
            "steps_per_s": steps / float(np.median(times)), "ms_per_step": 1e3 * float(np.median(times)) / steps,
            "numeric_warnings": int(warn), "state_finite": bool(np.isfinite(g.base_mu).all()),
            "sweep": "persistent launch" if g.sweep_counts()["persistent"] else "one launch per block step"}
+    if with_roofline:
+        # BASELINE config 3 (the MFMA / HBM roofline stress size): the P-update GEMM pair measured live like the headline's (HIP
+        # events on the handle's stream around 20 pairs replayed from a graph) and the per-stage device times of the step
+        n, m_pad = 22 + 3 * n_landmarks, ((2 * n_landmarks + 63) // 64) * 64
+        avg_us, flops_per_launch = g.profile_update_gemms(20)
+        tf = flops_per_launch / (avg_us * 1e-6) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "P-update GEMM pair (Sigma - K W, T + G K^T): gemm_f32_mfma_kernel, 64 x 64 tiles, three workgroups per compute unit",
+                           "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                           "flops_per_launch": flops_per_launch, "avg_launch_us": avg_us, "shape": {"M": n, "N": n, "K": m_pad},
+                           "traffic": None, "algorithmic_bytes_per_launch": 4.0 * (2.0 * n * m_pad + 2.0 * n * n),
+                           "note": "pairs replayed back to back from a graph on the filter's own operands; rocprofv3 means of the same launches inside the step: profiles/r05_kernel_stats_n1024.csv"}
+        for tag in ("r05",):
+            pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_n1024.json" % tag)
+            if n_landmarks == 1024 and os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if "p_update_gemm_traffic_bytes_per_launch" in pj:
+                    out["roofline"]["traffic"] = pj["p_update_gemm_traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_quoted_from_profiles"] = True
+                    out["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic_n1024.json" % tag
+        g.profile(True)
+        g.run_uploaded(warm, 6, sc.dt)
+        g.synchronize()
+        rep = g.profile_report()
+        g.profile(False)
+        out["stage_us_per_step"] = {k: 1e3 * v["ms"] / 6 for k, v in rep.items() if v["launches"]}
+        fl = step_flops(n_landmarks)
+        out["roofline_step"] = {"flops_per_step": fl["total"], "achieved": fl["total"] / (out["ms_per_step"] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                "unit": "TFLOP/s", "frac": fl["total"] / (out["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     if predict == "dense":
         # the two dense F P F^T GEMMs (north-star form): event-bracketed device time of the gemm_predict class over 10 steps
         g.profile(True)
@@ -545,15 +573,20 @@ def main():
         except Exception as ex:  # diagnostic extra, never fatal
             extra["roofline_stress_shape"] = {"error": str(ex)}
         extra["stage_us_per_step"] = {k: 1e3 * v["ms"] / args.profile_steps for k, v in rep.items() if v["launches"]}
+        if "gather" in extra["stage_us_per_step"] and g.sweep_counts()["persistent"]:
+            # with the fused persistent launch the "gather" scope holds only the update's bookkeeping kernel (the measurement gather itself
+            # is part of the persistent launch, scope "cholesky"): say so in the key
+            extra["stage_us_per_step"]["update_bookkeeping"] = extra["stage_us_per_step"].pop("gather")
         # The sweep is the longest launch of the step (half of it at N=256), and it is NOT the roofline kernel: its duration is
         # the latency of one workgroup's sequential pivot chain, stated here so that nobody has to infer it
         if "cholesky" in extra["stage_us_per_step"]:
             us_sweep = extra["stage_us_per_step"]["cholesky"]
             extra["roofline_sweep"] = {"bound": "latency (sequential pivot chain of one workgroup; DESIGN.md section 3)",
                                        "kernel": "gather + Cholesky sweep + gain tiles in one persistent launch (chol_persist_kernel where it applies, else gather, one launch per block step, gain kernel)",
-                                       "flops_per_step": fl["cholesky_sweep"], "stage_us": us_sweep,
-                                       "achieved": fl["cholesky_sweep"] / (us_sweep * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": fl["cholesky_sweep"] / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       "flops_per_step": fl["cholesky_sweep"] + fl["gain_gemm"], "flops_breakdown": {"cholesky_sweep": fl["cholesky_sweep"], "gain": fl["gain_gemm"]},
+                                       "stage_us": us_sweep,
+                                       "achieved": (fl["cholesky_sweep"] + fl["gain_gemm"]) / (us_sweep * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": (fl["cholesky_sweep"] + fl["gain_gemm"]) / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                        "note": "event-bracketed stage time of the eager, per-stage timed run (includes a few us of launch gaps); "
                                                "since round 4 the stage is ONE launch that also holds the measurement gather, the first diagonal tile and the gain's tiles "
                                                "(chol_persist_kernel, fused); in-kernel stamps: profiles/r04_cholesky_phase_stamps.txt"}
@@ -569,6 +602,8 @@ def main():
                   # with its depth variance 1000) and the north-star dense predict beside the structured one (report both)
                 extra["other_sizes"] = [device_resident_rate(30, local, depth_var=1000.0), device_resident_rate(100, local),
                                         device_resident_rate(400, local, depth_var=1000.0)]
+                # BASELINE config 3 (N = 1024: n = 3094, m = 2048), driver-timed, with the roofline of its P-update GEMMs
+                extra["config3_n1024"] = device_resident_rate(1024, local, steps=30, warm=6, with_roofline=True)
                 extra["predict_dense"] = device_resident_rate(N, local, steps=100, predict="dense")
                 extra["predict_dense"]["structured_steps_per_s_same_run"] = world * args.steps / elapsed
             except Exception as ex:
