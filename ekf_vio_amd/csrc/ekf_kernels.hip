@@ -35,8 +35,9 @@ __device__ inline V3 qrot(const Q4& q, const V3& v) {
     return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
 }
 // The reference is an x86-64 build of Eigen with its vectorisation on (CMakeLists.txt:15 overwrites the -msse* flags of
-// :9, so plain x86-64: SSE2, no SSE3 / FMA): the three functions below follow that build's rounding order, as
-// oracle/ekf_oracle.hpp does by default (Config::eigen_sse_quat; the other orders are variants the CPU tests compare).
+// :9, so plain x86-64: SSE2, no SSE3 / FMA): the three functions below follow that build's rounding order (the CPU
+// restatement used by the tests follows the same order by default and measures how far the other builds are away:
+// tests/test_oracle_variants_cpu.py).
 // Vector4f::squaredNorm() over the coefficients (x,y,z,w): a packet of squares reduced by SSE2 predux, (c0+c2)+(c1+c3)
 __device__ inline float squared_norm4(const Q4& q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
 __device__ inline Q4 qinverse(const Q4& q) {
