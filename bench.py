@@ -565,7 +565,10 @@ def main():
         try:
             import ctypes as C
             us = C.c_double(0)
-            if g.lib.ekfvio_test_gemm_bench(g.h, 1, 0, 3094, 3094, 2048, 20, 0, C.byref(us)) == 0 and us.value > 0:
+            gh = TightlyCoupledEKF(max_features=4, device=local, hooks=True)  # (a test hook: lives in the hooks build of the library, not in the product)
+            rc_h = gh.lib.ekfvio_test_gemm_bench(gh.h, 1, 0, 3094, 3094, 2048, 20, 0, C.byref(us))
+            gh.close()
+            if rc_h == 0 and us.value > 0:
                 tf = 2.0 * 3094 * 3094 * 2048 / (us.value * 1e-6) / 1e12
                 extra["roofline_stress_shape"] = {"shape": {"M": 3094, "N": 3094, "K": 2048}, "avg_launch_us": us.value,
                                                   "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

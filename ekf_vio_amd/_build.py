@@ -10,8 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libekfvio_hip.so")
+# the same sources with -DEKFVIO_TEST_HOOKS: the product library + include/ekfvio_test_hooks.h (raw kernels, stamps, fault injection).
+# Tests and profiling scripts that need those entry points load THIS one; the product library exports none of them.
+HOOKS_LIB_PATH = os.path.join(LIB_DIR, "libekfvio_hip_hooks.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
+HOOKS_OBJ_DIR = os.path.join(LIB_DIR, "obj_hooks")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
          "-ffp-contract=off",  # the reference's x86-64 build never fuses multiply-add (parity)
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -38,12 +42,12 @@ def _flags_key():
 def _stale():
     """Only meaningful while holding the build lock (a concurrent builder replaces the library atomically, but the
     object files and the flags stamp change underneath)."""
-    if not os.path.exists(LIB_PATH) or not os.path.exists(FLAGS_STAMP):
-        return True
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HOOKS_LIB_PATH) or not os.path.exists(FLAGS_STAMP) or not os.path.exists(ISA_STAMP):
+        return True  # (no ISA stamp: the hand-placed counted wait of chol.hip has not been checked against this library's compile)
     if open(FLAGS_STAMP).read() != _flags_key():
         return True  # e.g. a diagnostic build with pricing switches (wrong results) must not survive
-    t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
+    t = min(os.path.getmtime(LIB_PATH), os.path.getmtime(HOOKS_LIB_PATH))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), os.path.join(_HERE, "..", "include", "ekfvio_test_hooks.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -52,6 +56,7 @@ def build(force=False, verbose=False):
     into place: the ranks of a multi-GPU launch all come through here at import, and none of them can map a
     half-written library."""
     os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(HOOKS_OBJ_DIR, exist_ok=True)
     import fcntl
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -61,27 +66,28 @@ def build(force=False, verbose=False):
 
 
 def _build_locked(force, verbose):
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), __file__]
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), os.path.join(_HERE, "..", "include", "ekfvio_test_hooks.h"), __file__]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     if not os.path.exists(FLAGS_STAMP) or open(FLAGS_STAMP).read() != _flags_key():
         force = True  # objects built with other flags
-    jobs, objs = [], []
+    jobs, objs, hobjs = [], [], []
     for src in sources():
         name = os.path.basename(src)
-        obj = os.path.join(OBJ_DIR, name + ".o")
-        objs.append(obj)
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
-                and os.path.getmtime(obj) >= newest_hdr):
-            continue
-        extra = _extra_flags()
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + extra + ["-c", "-o", obj, src]
-        if verbose:
-            print(" ".join(cmd))
-        jobs.append((cmd, subprocess.Popen(cmd)))
+        for odir, define, olist in ((OBJ_DIR, [], objs), (HOOKS_OBJ_DIR, ["-DEKFVIO_TEST_HOOKS"], hobjs)):
+            obj = os.path.join(odir, name + ".o")
+            olist.append(obj)
+            if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+                    and os.path.getmtime(obj) >= newest_hdr):
+                continue
+            extra = _extra_flags()
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + extra + define + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
     # chol.hip carries a hand-placed, COUNTED wait (chol_persist.inc: ready[k] goes up behind `s_waitcnt vmcnt(N)`): the ISA of
     # the very compile that is being linked is checked, with the same flags, and the build fails on a mismatch
     isa_job = None
-    if any(os.path.basename(c[-1]) == "chol.hip" for c, _ in jobs) or not os.path.exists(ISA_STAMP):
+    if any(os.path.basename(c[-1]) == "chol.hip" and "-DEKFVIO_TEST_HOOKS" not in c for c, _ in jobs) or not os.path.exists(ISA_STAMP):
         src = os.path.join(CSRC, "chol.hip")
         isa = os.path.join(OBJ_DIR, "chol.device.s")
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get("chol.hip", []) + _extra_flags() + ["-S", "--cuda-device-only", "-o", isa, src]
@@ -102,12 +108,13 @@ def _build_locked(force, verbose):
             raise RuntimeError("chol.hip: hand-placed counted wait does not match the compiled ISA: " + "; ".join(problems))
         with open(ISA_STAMP, "w") as fh:
             fh.write("ok\n")
-    tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
-    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIB_PATH)  # atomic: a concurrent loader maps either the old or the new complete file
+    for path, olist in ((LIB_PATH, objs), (HOOKS_LIB_PATH, hobjs)):
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + olist
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, path)  # atomic: a concurrent loader maps either the old or the new complete file
     with open(FLAGS_STAMP + ".tmp", "w") as fh:
         fh.write(_flags_key())
     os.replace(FLAGS_STAMP + ".tmp", FLAGS_STAMP)
@@ -130,6 +137,10 @@ def check_counted_waits(isa_text):
     problems = []
     waits = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\((\d+)\)", l) and i > 0 and "ASMSTART" in lines[i - 1]]
     counted = [i for i in waits if int(re.search(r"vmcnt\((\d+)\)", lines[i]).group(1)) > 0]
+    if not counted:
+        # the chain's hit path raises ready[k] behind `s_waitcnt vmcnt(20)` (chol_persist.inc): if no counted inline-asm wait is found at all,
+        # the asm marker format has changed or the path has been restructured -- either way the guard below would check nothing
+        problems.append("no counted inline-asm s_waitcnt vmcnt(N > 0) found in chol_persist_kernel")
     for w in counted:
         want = int(re.search(r"vmcnt\((\d+)\)", lines[w]).group(1))
         # walk back over the straight-line code in front of the wait (the stores sit in front of the branch that leads here:
@@ -143,6 +154,16 @@ def check_counted_waits(isa_text):
                 break
         if loads != want:
             problems.append("vmcnt(%d) behind %d loads" % (want, loads))
+        # ... and the factor's write-through (sc1) stores must be what lies in front of those loads in program order: the nearest
+        # vector-memory store above the wait has to be an sc1 store
+        for i in range(w - 1, -1, -1):
+            l = lines[i].strip()
+            if re.match(r"(global|buffer|flat|scratch)_store", l):
+                if " sc1" not in l:
+                    problems.append("the store in front of vmcnt(%d) is not a write-through (sc1) store: %s" % (want, l))
+                break
+        else:
+            problems.append("no store in front of vmcnt(%d)" % want)
     return problems
 
 

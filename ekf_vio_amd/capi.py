@@ -1,5 +1,9 @@
 """ctypes binding of libekfvio_hip.so (include/ekfvio.h).  No fallback: a missing or
-unloadable library raises; nothing in this package computes on the CPU."""
+unloadable library raises; nothing in this package computes on the CPU.
+
+Two builds of the same sources (ekf_vio_amd/_build.py): the product library, which exports exactly what include/ekfvio.h
+declares, and libekfvio_hip_hooks.so, which adds include/ekfvio_test_hooks.h (raw kernels, in-kernel stamps, fault
+injection: tests and profiling scripts only).  load() is the product; load(hooks=True) the other."""
 import ctypes as C
 import os
 
@@ -36,30 +40,31 @@ SYMBOLS = ["ekfvio_default_config", "ekfvio_create", "ekfvio_destroy", "ekfvio_r
            "ekfvio_get_feature_cov", "ekfvio_get_depth_variance", "ekfvio_set_feature_cov", "ekfvio_metric2pixel_map",
            "ekfvio_pixel2metric_map", "ekfvio_get_odometry", "ekfvio_get_points", "ekfvio_check_sigma", "ekfvio_set_state",
            "ekfvio_klt_push_frame", "ekfvio_klt_track", "ekfvio_klt_track_points", "ekfvio_klt_get_level",
-           "ekfvio_klt_uncertainty_points", "ekfvio_step_image", "ekfvio_replenish", "ekfvio_fast_detect", "ekfvio_test_blurred_level0", "ekfvio_imu", "ekfvio_imu_update",
+           "ekfvio_klt_uncertainty_points", "ekfvio_step_image", "ekfvio_replenish", "ekfvio_fast_detect", "ekfvio_imu", "ekfvio_imu_update",
            "ekfvio_upload_measurements", "ekfvio_run_uploaded", "ekfvio_synchronize", "ekfvio_profile_enable",
            "ekfvio_profile_reset", "ekfvio_profile_count", "ekfvio_profile_name", "ekfvio_profile_get",
-           "ekfvio_profile_update_gemms", "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps", "ekfvio_test_sweep_stamps", "ekfvio_test_persistent_sweeps",
-           "ekfvio_test_sweep_counts", "ekfvio_test_early_output_frames", "ekfvio_test_sweep_fault",
-           "ekfvio_test_cholesky_solve", "ekfvio_test_klt_padded_level"]
+           "ekfvio_profile_update_gemms", "ekfvio_get_counters"]
+# every symbol include/ekfvio_test_hooks.h declares (libekfvio_hip_hooks.so only)
+HOOK_SYMBOLS = ["ekfvio_test_klt_padded_level", "ekfvio_test_blurred_level0", "ekfvio_test_gemm", "ekfvio_test_gemm_bench", "ekfvio_test_potrf_stamps",
+                "ekfvio_test_sweep_stamps", "ekfvio_test_sweep_fault", "ekfvio_test_cholesky_solve"]
 
-_lib = None
+_libs = {}
 
 
 def lib_path():
     return _build.LIB_PATH
 
 
-def load(build_if_missing=True):
-    """Loads the HIP library (building it with hipcc first if it is absent)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(build_if_missing=True, hooks=False):
+    """Loads the HIP library (building it with hipcc first if it is absent); hooks=True: the build with the test hooks."""
+    if hooks in _libs:
+        return _libs[hooks]
+    path = _build.HOOKS_LIB_PATH if hooks else _build.LIB_PATH
     if build_if_missing:
         _build.build()  # staleness is decided under the build lock; hipcc cross-compiles gfx950 with or without a GPU
-    elif not os.path.exists(_build.LIB_PATH):
-        raise FileNotFoundError(_build.LIB_PATH + " not built; run python -m ekf_vio_amd._build")
-    lib = C.CDLL(_build.LIB_PATH)
+    elif not os.path.exists(path):
+        raise FileNotFoundError(path + " not built; run python -m ekf_vio_amd._build")
+    lib = C.CDLL(path)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     fp, u8p, ip = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     sig = {
@@ -78,23 +83,26 @@ def load(build_if_missing=True):
         "ekfvio_klt_track_points": [vp, fp, fp, i32, fp, u8p],
         "ekfvio_klt_uncertainty_points": [vp, fp, fp, i32, fp],
         "ekfvio_klt_get_level": [vp, i32, ip, ip, u8p, C.POINTER(C.c_int16)],
-        "ekfvio_test_klt_padded_level": [vp, i32, ip, u8p, C.POINTER(C.c_int16)],
         "ekfvio_step_image": [vp, C.c_double, u8p, i32, i32, i32, fp], "ekfvio_imu": [vp, C.c_double, fp, fp], "ekfvio_imu_update": [vp, fp, fp],
-        "ekfvio_replenish": [vp, ip, ip], "ekfvio_fast_detect": [vp, i32, i32, i32, ip, ip, ip], "ekfvio_test_blurred_level0": [vp, u8p],
+        "ekfvio_replenish": [vp, ip, ip], "ekfvio_fast_detect": [vp, i32, i32, i32, ip, ip, ip],
         "ekfvio_upload_measurements": [vp, i32, fp, fp, u8p], "ekfvio_run_uploaded": [vp, i32, i32, f32],
         "ekfvio_synchronize": [vp], "ekfvio_profile_enable": [vp, i32], "ekfvio_profile_reset": [vp],
         "ekfvio_profile_count": [], "ekfvio_profile_name": [i32],
         "ekfvio_profile_get": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
         "ekfvio_profile_update_gemms": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
-        "ekfvio_test_gemm": [vp, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, i32],
-        "ekfvio_test_cholesky_solve": [vp, i32, i32, fp, fp, fp, fp, ip],
-        "ekfvio_test_potrf_stamps": [vp, C.POINTER(C.c_int64)],
-        "ekfvio_test_sweep_stamps": [vp, C.c_int, C.POINTER(C.c_int64)],
-        "ekfvio_test_persistent_sweeps": [vp, C.POINTER(C.c_int64)],
-        "ekfvio_test_sweep_counts": [vp, C.POINTER(C.c_int64)], "ekfvio_test_sweep_fault": [vp, i32, i32],
-        "ekfvio_test_early_output_frames": [vp, C.POINTER(C.c_int64)],
-        "ekfvio_test_gemm_bench": [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)],
+        "ekfvio_get_counters": [vp, C.POINTER(C.c_int64)],
     }
+    if hooks:
+        sig.update({
+            "ekfvio_test_klt_padded_level": [vp, i32, ip, u8p, C.POINTER(C.c_int16)],
+            "ekfvio_test_blurred_level0": [vp, u8p],
+            "ekfvio_test_gemm": [vp, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, i32],
+            "ekfvio_test_cholesky_solve": [vp, i32, i32, fp, fp, fp, fp, ip],
+            "ekfvio_test_potrf_stamps": [vp, C.POINTER(C.c_int64)],
+            "ekfvio_test_sweep_stamps": [vp, C.c_int, C.POINTER(C.c_int64)],
+            "ekfvio_test_sweep_fault": [vp, i32, i32],
+            "ekfvio_test_gemm_bench": [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)],
+        })
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -102,5 +110,5 @@ def load(build_if_missing=True):
     lib.ekfvio_last_error.argtypes = [vp]
     lib.ekfvio_last_error.restype = C.c_char_p
     lib.ekfvio_profile_name.restype = C.c_char_p
-    _lib = lib
+    _libs[hooks] = lib
     return lib

@@ -219,7 +219,7 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
     HIPC(f, dev_alloc(f->stream, &f->Laug, (size_t)f->ld_aug * f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Linv, 64 * (size_t)f->m_cap));
     HIPC(f, dev_alloc(f->stream, &f->Lsign, (size_t)(f->m_cap / 64 > 256 ? f->m_cap / 64 : 256)));  // 256: the raw-solve test hook goes up to m = 16384
-    {   // flags of the persistent sweeps (chol_persist.inc, chol_persist_la.inc): ready[mb] + 2 x [row blocks x mb] + abort word
+    {   // flags of the persistent sweeps (chol_persist.inc): ready[mb] + 2 x [row blocks x mb] + abort word
         const size_t mb2 = (size_t)(f->m_cap / 64);
         f->sweep_sync_words = std::max((size_t)1024, mb2 + 2 * (size_t)(f->ld_aug / 64 + 1) * mb2 + 8);  // (>= 1024: the test hooks sweep matrices that are not the filter's)
         HIPC(f, dev_alloc(f->stream, &f->sweep_sync, f->sweep_sync_words));
@@ -228,7 +228,9 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         hipDeviceProp_t prop;
         HIPC(f, hipGetDeviceProperties(&prop, device));
         f->num_cus = prop.multiProcessorCount;
-        const char* e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
+        const char* e = getenv("EKFVIO_SWEEP_RETRY_S");  // the first pause before a handle whose persistent sweep gave up tries it again (default 2 s)
+        if (e && atof(e) > 0) f->sweep_retry_first_s = atof(e);
+        e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
         if (e) f->sweep_mode = atoi(e) ? 2 : 0;
         e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
@@ -242,8 +244,6 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->persist_oversub = atoi(e);
         e = getenv("EKFVIO_EARLY_OUTPUTS");  // tuning knob: 0 = a frame's outputs behind its last kernel (rounds 1-3)
         if (e) f->early_outputs = atoi(e) ? 1 : 0;
-        e = getenv("EKFVIO_SWEEP_LA_PERSIST");  // experiment: 1 = the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
-        if (e) f->la_persist = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_GAIN");
         if (e) f->persist_gain = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_EARLY");
@@ -397,8 +397,23 @@ int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense) {
 // resident: another process or stream held compute units).  Behind an aborted sweep the Joseph GEMMs write nothing, so
 // Sigma, mu and the frame counter stand where process(dt) left them, and the handle stops using the persistent launch.
 void sweep_abort_latch(ekfvio_filter* f) {
-    f->sweep_mode = 0;  // every later sweep of this handle: one launch per block step (no co-residency needed)
+    f->sweep_mode = 0;  // the following sweeps of this handle: one launch per block step (no co-residency needed)
     drop_graph(f);      // captured steps contain the persistent launch
+    // ... and a way back: what kept the workgroups from being resident -- another process or stream on the device, a
+    // compute-unit mask -- may be gone later.  The persistent launch is tried again after a pause that doubles with every abort
+    // (2 s, 4 s, ... 64 s), checked at the entry points that enqueue updates (sweep_maybe_retry).
+    f->sweep_retry_pause_s = f->sweep_retry_pause_s <= 0 ? f->sweep_retry_first_s : std::min(64.0, 2.0 * f->sweep_retry_pause_s);
+    f->sweep_retry_at = std::chrono::steady_clock::now() + std::chrono::milliseconds((long long)(1e3 * f->sweep_retry_pause_s));
+    f->sweep_retry_armed = true;
+}
+void sweep_maybe_retry(ekfvio_filter* f) {
+    if (!f->sweep_retry_armed || f->sweep_mode != 0 || std::chrono::steady_clock::now() < f->sweep_retry_at) return;
+    f->sweep_retry_armed = false;
+    f->sweep_mode = 2;
+    drop_graph(f);  // captured steps contain the per-step sweep
+    // the flags AND the abort word (which no kernel ever zeroes) start from zero again
+    (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * f->sweep_sync_words, f->stream);
+    f->sweep_flags_clean = false;
 }
 // Waits for the stream and reads the status word.  An aborted update is enqueued again by `rerun` (null: the caller cannot,
 // e.g. a graph replay of many steps: EKFVIO_EABORTED) with the per-step sweep and awaited: fresh launches, same inputs,
@@ -435,6 +450,7 @@ int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_
     f->out_fresh = false;
     if (count > 0 && (!z || !R || !pass)) return EKFVIO_EINVAL;
     HIPC(f, hipSetDevice(f->device));
+    sweep_maybe_retry(f);
     const int m = count_rows(pass, count);
     // the frame's three host arrays travel as ONE copy from pinned memory (three pageable copies cost ~25 us per step);
     // the previous call's synchronisation (finish_update) guarantees the staging buffer is free
@@ -698,6 +714,12 @@ static void drop_graph(ekfvio_filter* f) {
 static int capture_steps(ekfvio_filter* f, int steps, int m, float dt, int* counter, hipGraphExec_t* out) {
     hipGraph_t g = nullptr;
     HIPC(f, hipStreamSynchronize(f->stream));
+    // sweep_flags_clean mirrors DEVICE state on the host, and a capture records launches without running them: the
+    // graph must not inherit the mirror's value of the moment it was captured at -- its first sweep always zeroes the flags itself (one
+    // memset node per replay) -- and the mirror must come out of the capture as it went in.  What a replay leaves behind is recorded
+    // separately (graph_leaves_flags_clean) and applied after every hipGraphLaunch.
+    const bool mirror = f->sweep_flags_clean;
+    f->sweep_flags_clean = false;
     HIPC(f, hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
     for (int k = 0; k < steps; k++) {
         // the frame's measurement bookkeeping rides in the process(dt) launch
@@ -706,6 +728,8 @@ static int capture_steps(ekfvio_filter* f, int steps, int m, float dt, int* coun
         launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames, true);
     }
     hipError_t ce = hipStreamEndCapture(f->stream, &g);
+    f->graph_leaves_flags_clean = f->sweep_flags_clean;  // (the same for every step count: the last update's last GEMM decides)
+    f->sweep_flags_clean = mirror;
     if (ce != hipSuccess || !g) {
         f->last_error = std::string("graph capture: ") + hipGetErrorString(ce);
         return EKFVIO_EDEVICE;
@@ -719,6 +743,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
     if (!f || f->seq_frames <= 0 || f->seq_N != f->N || count < 0 || first < 0 || !(dt >= 0.f)) return EKFVIO_EINVAL;
     f->out_fresh = false;
     HIPC(f, hipSetDevice(f->device));
+    sweep_maybe_retry(f);
     const size_t N = f->N;
     int s = 0;
     // hipGraph path: the same measurement-row count for every frame (one launch geometry),
@@ -753,6 +778,7 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
             for (; s + EKF_GRAPH_STEPS_BIG <= count; s += EKF_GRAPH_STEPS_BIG) HIPC(f, hipGraphLaunch(f->step_graph_big, f->stream));
         for (; s + EKF_GRAPH_STEPS <= count; s += EKF_GRAPH_STEPS) HIPC(f, hipGraphLaunch(f->step_graph, f->stream));
         for (; s + 2 <= count; s += 2) HIPC(f, hipGraphLaunch(f->step_graph_pair, f->stream));
+        if (s > 0) f->sweep_flags_clean = f->graph_leaves_flags_clean;  // what the last replayed step left in device memory
         for (; s < count; s++) {  // an odd last step, eager, same counter-driven bookkeeping
             launch_predict(f, dt);
             launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames);
@@ -847,6 +873,18 @@ int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t*
     return EKFVIO_OK;
 }
 
+int ekfvio_get_counters(ekfvio_filter* f, int64_t counters[8]) {
+    if (!f || !counters) return EKFVIO_EINVAL;
+    counters[0] = f->persistent_sweeps;
+    counters[1] = f->schur_sweeps;
+    counters[2] = f->sweep_recoveries;
+    counters[3] = f->sweep_mode;
+    counters[4] = f->early_output_frames;
+    counters[5] = counters[6] = counters[7] = 0;
+    return EKFVIO_OK;
+}
+
+#ifdef EKFVIO_TEST_HOOKS  // include/ekfvio_test_hooks.h: only in libekfvio_hip_hooks.so
 // ---- raw kernels for unit tests -------------------------------------------------------
 int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
                      int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc, int32_t variant) {
@@ -983,27 +1021,6 @@ int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t* stamps /* [1
     return EKFVIO_OK;
 }
 
-int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count) {
-    if (!f || !count) return EKFVIO_EINVAL;
-    *count = f->persistent_sweeps;
-    return EKFVIO_OK;
-}
-
-int ekfvio_test_early_output_frames(ekfvio_filter* f, int64_t* count) {
-    if (!f || !count) return EKFVIO_EINVAL;
-    *count = f->early_output_frames;
-    return EKFVIO_OK;
-}
-
-int ekfvio_test_sweep_counts(ekfvio_filter* f, int64_t counts[4]) {
-    if (!f || !counts) return EKFVIO_EINVAL;
-    counts[0] = f->persistent_sweeps;
-    counts[1] = f->schur_sweeps;
-    counts[2] = f->sweep_recoveries;
-    counts[3] = f->sweep_mode;
-    return EKFVIO_OK;
-}
-
 int ekfvio_test_sweep_fault(ekfvio_filter* f, int32_t spin_limit, int32_t stall_workgroup) {
     if (!f || spin_limit < 0) return EKFVIO_EINVAL;
     f->sweep_spin_limit = spin_limit;
@@ -1071,5 +1088,6 @@ int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const 
     hipFree(dW);
     return EKFVIO_OK;
 }
+#endif  // EKFVIO_TEST_HOOKS
 
 }  // extern "C"

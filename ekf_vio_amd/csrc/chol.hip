@@ -627,7 +627,8 @@ __device__ __attribute__((noinline)) unsigned long long potrf64_signed(float* A,
     return neg;
 }
 
-// Diagnostic twin of potrf64_kernel: same work, s_memtime stamps after every phase.
+// Diagnostic twin of potrf64_kernel: same work, s_memtime stamps after every phase (hooks build only).
+#ifdef EKFVIO_TEST_HOOKS
 template <int FV>
 __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
                                                             int ldl, float* __restrict__ Linv, long long* stamps, int passes) {
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(256) void potrf64_stamp_kernel(const float* __restr
         if (tid == 0) stamps[11] = (long long)__builtin_amdgcn_s_memtime();
     }
 }
+#endif  // EKFVIO_TEST_HOOKS
 
 // Factor the first diagonal block (step "-1" of the sweep).
 __global__ __launch_bounds__(256) void potrf64_kernel(const float* __restrict__ S, int lds, float* __restrict__ L,
@@ -1074,14 +1076,18 @@ __global__ __launch_bounds__(256) void sign_irows_kernel(float* __restrict__ L, 
 }
 
 
-// every wait inside the persistent sweep is bounded by this many polls (chol_persist.inc)
-#define SWEEP_SPIN_LIMIT (1 << 22)
+// Every wait inside the persistent sweep is bounded (chol_persist.inc, persist_poll): by wall-clock time, SWEEP_WAIT_TICKS of the
+// 100 MHz s_memrealtime counter = 3 ms (a filter step is 0.1 ms, the longest legitimate wait ~10 us), and by a number of looks that only
+// the fault-injection hook lowers into reach.
+#define SWEEP_SPIN_LIMIT (1 << 30)
+#define SWEEP_WAIT_TICKS 300000
 
 #include "chol_persist.inc"
-#include "chol_persist_la.inc"
+#include "chol_step_la.inc"
 
 }  // namespace
 
+#ifdef EKFVIO_TEST_HOOKS
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps) {
     const char* e = getenv("EKFVIO_POTRF_FV");  // diagnostic: which factor-phase variant to time
     const int fv = e ? atoi(e) : EKF_POTRF_FV;
@@ -1090,6 +1096,7 @@ void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, flo
     const char* w = getenv("EKFVIO_POTRF_WARM");
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, f->stream, S, ld, L, ld, Linv, d_stamps, (w && atoi(w)) ? 2 : 1);
 }
+#endif  // EKFVIO_TEST_HOOKS
 
 // layout: ready[mb], fin[rows x mb], pan[rows x mb] (panel blocks of the X / identity rows, for the gain tiles formed inside the
 // launch), one spare word, the abort word (last: whoever zeroes the flags for the next sweep leaves it alone, persist_zero_words);
@@ -1159,27 +1166,6 @@ static bool persist_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
 static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     return persist_shape(f, m_pad, n_pad) && 1 + mb * (f->ldp / 64) + 2 + persist_helpers(mb, n_pad / PB) <= f->num_cus + 8;
-}
-// The split sweep as one persistent launch (chol_persist_la.inc): the grid is every workgroup slot of the device (the occupancy
-// query's workgroups per compute unit x compute units: all must be resident, they wait for each other), admitted when the round-robin
-// deal gives a workgroup at most LA_MAX_TILES tiles and the flags fit; 0 = run the rounds as launches (the default).
-static int la_persist_grid(ekfvio_filter* f, int m_pad, int n_pad) {
-    const bool on = f->la_persist != 0;  // EKFVIO_SWEEP_LA_PERSIST=1 (opt-in: measured, not faster -- profiles/r04_persistent_split_sweep_experiment.txt)
-    const int mb = m_pad / PB, rb = n_pad / PB + mb;
-    if (!on || f->sweep_mode != 2 || mb < EKF_SWEEP_SPLIT_MB || live_handles_on(f->device) > 1 ||
-        persist_flag_words(m_pad, n_pad) > f->sweep_sync_words)
-        return 0;
-    if (f->la_persist_occupancy < 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(chol_persist_la_kernel), 256, 0) != hipSuccess) nb = 0;
-        f->la_persist_occupancy = nb;
-    }
-    const int grid = f->la_persist_occupancy * f->num_cus;
-    int tiles = 0;  // far owners' tiles: block columns >= 3
-    for (int j = 3; j < mb; j++) tiles += mb - j + rb;
-    const int general = grid - 4 - (mb + rb - 2);  // without the chain's compute unit and the row workers
-    if (general < 64 || (tiles + general - 1) / general > LA_MAX_TILES) return 0;
-    return grid;
 }
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
@@ -1286,25 +1272,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         LaArgs la;
         la.S = Saug, la.lds = ld, la.L = Laug, la.ldl = ld, la.Linv = Linv;
         la.mb = mb, la.rb = rb, la.idb0 = idb0, la.info = f->info, la.Lsign = f->Lsign;
-        const int la_grid = la_persist_grid(f, m_pad, n_pad);
-        if (la_grid > 0) {
-            // ONE launch for all block steps (chol_persist_la.inc): tile owners, hand-offs through flags
-            PersistArgs pa;
-            persist_flag_pointers(f, pa, mb, mb + rb);
-            LaSync y;
-            y.ready = pa.ready, y.near_done = pa.fin, y.far_done = pa.pan, y.abort_flag = pa.abort_flag;
-            y.nrows = mb + rb;
-            y.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
-            y.stall_wg = f->sweep_stall_wg;
-            y.dbg = f->sweep_dbg;
-            y.ticket = pa.fin + (mb - 1) * (mb + rb);  // (the unused tail of the near_done block: zeroed with the flags)
-            y.chain_key = y.ticket + 1;
-            f->sweep_abort_word = pa.abort_flag;
-            if (!f->sweep_flags_clean) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
-            f->sweep_flags_clean = false;
-            hipLaunchKernelGGL(chol_persist_la_kernel, dim3(la_grid), dim3(256), 0, f->stream, la, y);
-            f->persistent_sweeps++;
-        } else {
+        {
             for (int l = 0; l + 1 < mb; l++) {
                 const int r = mb - 1 - l;
                 int far = 0;  // columns l+2, l+4, ... from the diagonal down plus the extra rows

@@ -4,10 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
 #include "../../include/ekfvio.h"
+#ifdef EKFVIO_TEST_HOOKS
+#include "../../include/ekfvio_test_hooks.h"
+#endif
 
 #define EKF_BASE 22
 #define EKF_TILE 64  // block size of every blocked algorithm (GEMM tile edge, Cholesky nb)
@@ -110,11 +114,13 @@ struct ekfvio_filter {
     int between_joseph_seq = 0;       // ... and the status sequence number its launch publishes (0: not called)
     long long early_output_frames = 0;  // frames whose outputs went out that way (test hook)
     int publish_after_sweep_seq = 0;  // ekfvio_update: launch_update publishes the status word with this sequence number right behind the sweep (0: not asked)
-    int la_persist = 0;               // EKFVIO_SWEEP_LA_PERSIST: the split sweep (N >= 512) as one persistent launch (chol_persist_la.inc)
-    int la_persist_occupancy = -1;    // workgroups of chol_persist_la_kernel per compute unit (occupancy query, once)
     int sweep_spin_limit = 0;         // > 0: looks per wait of the persistent sweep (test hook ekfvio_test_sweep_fault); 0: SWEEP_SPIN_LIMIT
     int sweep_stall_wg = -1;          // fault injection: this workgroup of the persistent launch never raises its flag
     const int* sweep_abort_word = nullptr;  // abort word of the persistent sweep enqueued last by launch_chol_sweep (null: another sweep)
+    bool sweep_retry_armed = false;    // an aborted persistent sweep latched sweep_mode to 0: tried again at sweep_retry_at (api.hip, sweep_maybe_retry)
+    double sweep_retry_pause_s = 0.0, sweep_retry_first_s = 2.0;
+    std::chrono::steady_clock::time_point sweep_retry_at;
+    bool graph_leaves_flags_clean = false;  // sweep_flags_clean as a replay of the captured step graphs leaves it (api.hip, capture_steps)
     bool sweep_flags_clean = false;   // the persistent sweep's flags are zero for the launch enqueued next (zeroed by the last GEMM of the
                                       // previous update, or by gather_potrf_kernel in front); otherwise the launcher enqueues a memset
     int fuse_sweep = 1;               // 1: gather + first diagonal tile + sweep in ONE launch where the persistent sweep applies (EKFVIO_FUSE_SWEEP)
@@ -306,6 +312,7 @@ int next_status_seq(ekfvio_filter* f);
 // api.hip: what a host does when the status word says the persistent sweep gave up (bit 1): the handle goes to the per-step
 // sweep for good and its captured graphs are dropped
 void sweep_abort_latch(ekfvio_filter* f);
+void sweep_maybe_retry(ekfvio_filter* f);  // at the entry points that enqueue updates: the persistent sweep again, some time after an abort
 int poll_status(ekfvio_filter* f, int seq, int* status, int* extra_out);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device
 int add_features_device(ekfvio_filter* f, int k);

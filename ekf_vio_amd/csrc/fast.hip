@@ -521,6 +521,7 @@ int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int3
 }
 
 // Test hook: the Gaussian-blurred level 0 the last FAST run saw (w*h bytes, tightly packed); needs cfg.fast_blur_sigma != 0.
+#ifdef EKFVIO_TEST_HOOKS  // include/ekfvio_test_hooks.h: only in libekfvio_hip_hooks.so
 int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out) {
     if (!f || !out) return EKFVIO_EINVAL;
     const KltFrame& fr = f->frames[f->cur];
@@ -530,6 +531,7 @@ int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out) {
     HIPF(f, hipStreamSynchronize(f->stream));
     return EKFVIO_OK;
 }
+#endif
 
 // EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame
 int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy) {

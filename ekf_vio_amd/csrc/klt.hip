@@ -1321,6 +1321,7 @@ int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h
     return EKFVIO_OK;
 }
 
+#ifdef EKFVIO_TEST_HOOKS  // include/ekfvio_test_hooks.h: only in libekfvio_hip_hooks.so
 int ekfvio_test_klt_padded_level(ekfvio_filter* f, int32_t level, int32_t* border, uint8_t* img, int16_t* deriv) {
     if (!f || level < 0) return EKFVIO_EINVAL;
     const KltFrame& fr = f->frames[f->cur];
@@ -1335,6 +1336,7 @@ int ekfvio_test_klt_padded_level(ekfvio_filter* f, int32_t level, int32_t* borde
     HIPK(f, hipStreamSynchronize(f->stream));
     return EKFVIO_OK;
 }
+#endif
 
 // EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) minus ROS publishing; with
 // cfg.replenish the FAST replenishment of :154 / :172 runs on the device too (otherwise the caller
@@ -1351,6 +1353,7 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
     // everything that can refuse the frame (sizes, capacity growth) comes before the first launch
     int rc = push_frame_check(f, image, width, height, stride, K);
     if (rc != EKFVIO_OK) return rc;
+    sweep_maybe_retry(f);
     const float dt = first ? 0.f : (float)(stamp - f->t_stamp);
     // an error return from here on has work enqueued behind it: wait for it (the pinned frame buffer is rewritten by the
     // next call) and leave the stamp with the state it belongs to

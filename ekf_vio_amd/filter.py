@@ -25,8 +25,10 @@ def _u8(a):
 class TightlyCoupledEKF:
     def __init__(self, max_features=100, device=0, stream=None, predict_mode=capi.PREDICT_STRUCTURED,
                  default_point_depth=0.5, default_point_depth_variance=100.0,
-                 default_point_homogenous_variance=1e-5, **cfg_overrides):
-        self.lib = capi.load()
+                 default_point_homogenous_variance=1e-5, hooks=False, **cfg_overrides):
+        # hooks=True: this handle lives in libekfvio_hip_hooks.so, the build that also has include/ekfvio_test_hooks.h (tests, profiling scripts)
+        self.hooks = bool(hooks)
+        self.lib = capi.load(hooks=self.hooks)
         cfg = capi.Config()
         self._chk(self.lib.ekfvio_default_config(C.byref(cfg)))
         cfg.max_features = max_features
@@ -220,7 +222,8 @@ class TightlyCoupledEKF:
 
     # ---- raw kernels -------------------------------------------------------------------
     def test_gemm(self, A, B, C0, alpha=1.0, beta=0.0, transB=True, variant=0):
-        """C = beta*C0 + alpha * A @ (B.T if transB else B); arrays are numpy [row, col]."""
+        """C = beta*C0 + alpha * A @ (B.T if transB else B); arrays are numpy [row, col].  (hooks build)"""
+        self._need_hooks()
         A = np.asarray(A, np.float32)
         B = np.asarray(B, np.float32)
         M, K = A.shape
@@ -231,24 +234,33 @@ class TightlyCoupledEKF:
                                             _fp(Cc), M, int(variant)))
         return Cc.T.copy()
 
+    def counters(self):
+        """ekfvio_get_counters: dict(persistent, schur, recoveries, mode, early_output_frames)."""
+        c = (C.c_int64 * 8)()
+        self._chk(self.lib.ekfvio_get_counters(self.h, c))
+        return dict(persistent=int(c[0]), schur=int(c[1]), recoveries=int(c[2]), mode=int(c[3]), early_output_frames=int(c[4]))
+
+    def _need_hooks(self):
+        if not self.hooks:
+            raise RuntimeError("this entry point exists only in the hooks build: construct the filter with hooks=True")
+
     def persistent_sweeps(self):
         """Diagnostic: sweeps of this handle that went out as the single persistent launch so far."""
-        c = C.c_int64(0)
-        self._chk(self.lib.ekfvio_test_persistent_sweeps(self.h, C.byref(c)))
-        return int(c.value)
+        return self.counters()["persistent"]
 
     def sweep_counts(self):
-        """Diagnostic: dict(persistent, schur, recoveries, mode) of this handle's Cholesky sweeps (ekfvio_test_sweep_counts)."""
-        c = (C.c_int64 * 4)()
-        self._chk(self.lib.ekfvio_test_sweep_counts(self.h, c))
-        return dict(persistent=int(c[0]), schur=int(c[1]), recoveries=int(c[2]), mode=int(c[3]))
+        """Diagnostic: dict(persistent, schur, recoveries, mode) of this handle's Cholesky sweeps."""
+        c = self.counters()
+        return {k: c[k] for k in ("persistent", "schur", "recoveries", "mode")}
 
     def sweep_fault(self, spin_limit=0, stall_workgroup=-1):
-        """Fault injection for the persistent sweep (ekfvio_test_sweep_fault)."""
+        """Fault injection for the persistent sweep (ekfvio_test_sweep_fault; hooks build)."""
+        self._need_hooks()
         self._chk(self.lib.ekfvio_test_sweep_fault(self.h, int(spin_limit), int(stall_workgroup)))
 
     def test_cholesky_solve(self, S, Crhs):
-        """Returns (L, X = Crhs @ inv(S), info)."""
+        """Returns (L, X = Crhs @ inv(S), info).  (hooks build)"""
+        self._need_hooks()
         S = np.asarray(S, np.float32)
         Crhs = np.asarray(Crhs, np.float32)
         m, nr = S.shape[0], Crhs.shape[0]

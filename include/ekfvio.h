@@ -179,9 +179,6 @@ int ekfvio_klt_uncertainty_points(ekfvio_filter* f, const float* ref_px, const f
 /* Test hook: interior of pyramid level `level` of the current frame (8-bit image, w*h, and
  * interleaved int16 Scharr dx,dy, w*h*2).  Either output may be NULL. */
 int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h, uint8_t* img, int16_t* deriv);
-/* Test hook: the same level WITH its border as the tracker reads it: (w + 2 border) x (h + 2 border) image bytes
- * (reflect-101 border) and int16 pairs (zero border).  `border` (may be NULL) receives the border width (24). */
-int ekfvio_test_klt_padded_level(ekfvio_filter* f, int32_t level, int32_t* border, uint8_t* img, int16_t* deriv);
 
 /* EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) without the ROS
  * publishing: first frame only stores the image and stamp; later frames run
@@ -206,8 +203,6 @@ int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy);
  * TYPE_9_16, keypoints in raster order. */
 int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score,
                        int32_t* count);
-/* Test hook: the blurred level 0 (w*h bytes) the last FAST run saw; cfg.fast_blur_sigma must be non-zero. */
-int ekfvio_test_blurred_level0(ekfvio_filter* f, uint8_t* out);
 /* EKFVIO::imu_callback (EKFVIO.cpp:113-115), a logging stub in the reference: with cfg.use_imu = 0 (default) this does
  * nothing.  With cfg.use_imu = 1 the record first propagates the filter to its stamp -- process(dt = stamp - t),
  * the reference's motion model; the first record or frame only sets t -- and then updates with z = [gyro; accel],
@@ -244,29 +239,12 @@ int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t*
  * state is untouched.  flops_per_launch = 2 n n m_pad (may be NULL). */
 int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_launch_us, double* flops_per_launch);
 
-/* Raw kernels for unit tests (column-major, device copies made internally).  variant: 0 = the
- * production tile choice, 1 / 2 = 64x64 tiles with 256 / 512 threads, 32 / 48 / 64 = BM x 64 tiles. */
-int ekfvio_test_gemm(ekfvio_filter* f, int32_t transB, int32_t M, int32_t N, int32_t K, float alpha, const float* A,
-                     int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc, int32_t variant);
-/* Mean time (us) of `reps` back-to-back GEMM launches at one shape, operands resident. */
-int ekfvio_test_gemm_bench(ekfvio_filter* f, int32_t transB, int32_t lowerB, int32_t M, int32_t N, int32_t K,
-                           int32_t reps, int32_t variant, double* mean_us);
-/* Diagnostic: s_memtime stamps of the phases of one 64x64 diagonal-block factorisation. */
-int ekfvio_test_potrf_stamps(ekfvio_filter* f, int64_t stamps[80]);
-int ekfvio_test_sweep_stamps(ekfvio_filter* f, int enable, int64_t stamps[1024]);
-/* Diagnostic: how many Cholesky sweeps of this handle went out as the single persistent launch (chol_persist_kernel) so far;
-   the others took one launch per block step.  Lets a test check which path it has exercised. */
-int ekfvio_test_persistent_sweeps(ekfvio_filter* f, int64_t* count);
-/* Diagnostic: counts[0] persistent sweeps, [1] sweeps with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1), [2] updates run
-   again behind an aborted persistent sweep, [3] the handle's sweep mode now (2: persistent where it applies, 0: per-step). */
-int ekfvio_test_sweep_counts(ekfvio_filter* f, int64_t counts[4]);
-/* Diagnostic: frames of ekfvio_step_image whose outputs and status were published between the update's two Joseph GEMMs. */
-int ekfvio_test_early_output_frames(ekfvio_filter* f, int64_t* count);
-/* Fault injection for the persistent sweep: at most `spin_limit` looks per wait (0: the production limit), and workgroup
-   `stall_workgroup` of the launch never raises its tile's flag (-1: none), so every wait behind it runs out. */
-int ekfvio_test_sweep_fault(ekfvio_filter* f, int32_t spin_limit, int32_t stall_workgroup);
-int ekfvio_test_cholesky_solve(ekfvio_filter* f, int32_t m, int32_t nrhs, const float* S, const float* Crhs,
-                               float* L_out, float* X_out, int32_t* info);
+/* Diagnostic counters of a handle (no device work): counters[0] Cholesky sweeps that went out as the single persistent launch
+ * (chol_persist_kernel; the others took one launch per block step), [1] sweeps with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1),
+ * [2] updates run again behind an aborted persistent sweep, [3] the handle's sweep mode now (2: persistent where it applies, 0: one launch
+ * per block step), [4] frames of ekfvio_step_image whose outputs and status were published between the update's two Joseph GEMMs,
+ * [5..7] reserved (0). */
+int ekfvio_get_counters(ekfvio_filter* f, int64_t counters[8]);
 
 #ifdef __cplusplus
 }

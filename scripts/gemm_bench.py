@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ekf_vio_amd import TightlyCoupledEKF  # noqa: E402
 
-g = TightlyCoupledEKF(max_features=4)
+g = TightlyCoupledEKF(max_features=4, hooks=True)
 shapes = [("joseph N=256", 1, 0, 790, 790, 512), ("gain   N=256", 1, 1, 790, 512, 512), ("gainNN N=256", 0, 1, 790, 512, 512),
           ("joseph N=64 ", 1, 0, 214, 214, 128), ("joseph N=1024", 1, 0, 3094, 3094, 2048), ("square 4096", 1, 0, 4096, 4096, 4096)]
 variants = [int(v) for v in (sys.argv[1:] or ["0"])]

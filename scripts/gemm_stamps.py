@@ -1,7 +1,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ekf_vio_amd import TightlyCoupledEKF
-g = TightlyCoupledEKF(max_features=4)
+g = TightlyCoupledEKF(max_features=4, hooks=True)
 for variant in [int(a) + 10000 for a in (sys.argv[1:] or ['1', '48'])]:
     buf = (C.c_double * 41)()
     rc = g.lib.ekfvio_test_gemm_bench(g.h, 1, 0, 790, 790, 512, 20, variant, buf)

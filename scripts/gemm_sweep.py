@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ekf_vio_amd import TightlyCoupledEKF  # noqa: E402
 
-g = TightlyCoupledEKF(max_features=4)
+g = TightlyCoupledEKF(max_features=4, hooks=True)
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 for M, N in [(64, 64), (128, 128), (790, 790), (1024, 1024), (2048, 2048)]:
     row = []

@@ -37,7 +37,7 @@ def gaps(tag, g, o32, o64):
 def main():
     out = []
     # raw GEMM
-    g = TightlyCoupledEKF(max_features=64)
+    g = TightlyCoupledEKF(max_features=64, hooks=True)
     rng = np.random.default_rng(0)
     for (M, N, K, tb) in [(64, 64, 16, True), (130, 70, 48, True), (200, 64, 64, False), (790, 790, 512, True), (257, 129, 80, False)]:
         A = rng.standard_normal((M, K)).astype(np.float32)
@@ -60,7 +60,7 @@ def main():
 
     for N, steps in [(3, 5), (30, 20), (100, 30)]:
         sc = Scenario(N, seed=0, dt=0.05)
-        g = TightlyCoupledEKF(max_features=N)
+        g = TightlyCoupledEKF(max_features=N, hooks=True)
         o32, o64 = OracleFilter(np.float32), OracleFilter(np.float64)
         uv = sc.initial_features()
         g.addNewFeatures(uv), o32.add_new_features(uv), o64.add_new_features(uv)
@@ -114,7 +114,7 @@ def main():
     # timing + profile at N=256
     N = 256
     sc = Scenario(N, seed=0)
-    g = TightlyCoupledEKF(max_features=N)
+    g = TightlyCoupledEKF(max_features=N, hooks=True)
     g.addNewFeatures(sc.initial_features())
     fr = list(sc.frames(40))
     g.upload_measurements(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))

@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 xs, ys = np.linspace(80, 560, 16), np.linspace(60, 420, n // 16)
 pts = np.array([[x, y] for y in ys for x in xs], np.float32)
 for iters in (1, 2, 5, 30):
-    v = EKFVIO(max_features=n, klt_max_iterations=iters)
+    v = EKFVIO(max_features=n, klt_max_iterations=iters, hooks=True)
     v.tracker.push_frame(a, K)
     v.tracker.push_frame(b, K)
     v.tc_ekf.profile(True)
@@ -24,7 +24,7 @@ for iters in (1, 2, 5, 30):
     v.tc_ekf.close()
 
 import ctypes as C
-v = EKFVIO(max_features=n)
+v = EKFVIO(max_features=n, hooks=True)
 v.tracker.push_frame(a, K)
 v.tracker.push_frame(b, K)
 v.tc_ekf.lib.ekfvio_test_sweep_stamps(v.tc_ekf.h, 1, None)
@@ -56,7 +56,7 @@ print("  durations by tile row (us): " + " ".join("%.1f" % x for x in d.mean(axi
 print("  durations of tile row 0: " + " ".join("%.1f" % x for x in d[0]))
 
 # the node's default geometry: a 640x480 upload resized by 4 inside the pyramid kernel (20 workgroups, 3 levels)
-v4 = EKFVIO(max_features=n, inverse_image_scale=4)
+v4 = EKFVIO(max_features=n, inverse_image_scale=4, hooks=True)
 v4.tracker.push_frame(a, K)
 v4.tc_ekf.lib.ekfvio_test_sweep_stamps(v4.tc_ekf.h, 1, None)
 v4.tracker.push_frame(b, K)

@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     Q = rng.standard_normal((m, m))
     S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
     Cr = rng.standard_normal((nr, m)).astype(np.float32)
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     L, X, info = g.test_cholesky_solve(S, Cr)
     np.save(sys.argv[4] + "_L.npy", L); np.save(sys.argv[4] + "_X.npy", X)
     print("info", info)

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ekf_vio_amd import TightlyCoupledEKF
-g = TightlyCoupledEKF(max_features=4)
+g = TightlyCoupledEKF(max_features=4, hooks=True)
 for fv in (sys.argv[1:] or ["0", "8", "10", "12", "13"]):
     os.environ["EKFVIO_POTRF_FV"] = fv
     best = None

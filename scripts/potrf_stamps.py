@@ -1,7 +1,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ekf_vio_amd import TightlyCoupledEKF
-g = TightlyCoupledEKF(max_features=4)
+g = TightlyCoupledEKF(max_features=4, hooks=True)
 st = (C.c_int64 * 80)()
 import sys as _s
 reps = int(_s.argv[1]) if len(_s.argv) > 1 else 3

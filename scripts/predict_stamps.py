@@ -5,7 +5,7 @@ from ekf_vio_amd import TightlyCoupledEKF
 from ekf_vio_amd.sim import Scenario
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sc = Scenario(N, seed=0)
-g = TightlyCoupledEKF(max_features=N)
+g = TightlyCoupledEKF(max_features=N, hooks=True)
 g.addNewFeatures(sc.initial_features())
 g.lib.ekfvio_test_sweep_stamps(g.h, 1, None)
 for z, R, p in sc.frames(5):

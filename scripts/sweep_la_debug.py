@@ -9,7 +9,7 @@ if len(sys.argv) > 1:
     A = rng.standard_normal((m, m)).astype(np.float32)
     S = (A @ A.T / m + np.eye(m, dtype=np.float32)).astype(np.float32)
     Cr = rng.standard_normal((nr, m)).astype(np.float32)
-    g = TightlyCoupledEKF(max_features=m // 2)
+    g = TightlyCoupledEKF(max_features=m // 2, hooks=True)
     L, X, info = g.test_cholesky_solve(S, Cr)
     np.save(sys.argv[1], np.concatenate([L.ravel(), X.ravel(), [info]]))
     Lr = np.linalg.cholesky(S.astype(np.float64))

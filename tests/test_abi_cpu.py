@@ -20,7 +20,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.lib_path()]).decode()
     exported = set(re.findall(r"\bT (ekfvio_[a-z0-9_]+)", out))
-    assert declared <= exported
+    # the product library exports EXACTLY the boundary: no test hook, no fault injector
+    assert declared == exported, declared ^ exported
+
+
+def test_hooks_build_adds_exactly_the_test_hooks_header():
+    """libekfvio_hip_hooks.so = the same sources with -DEKFVIO_TEST_HOOKS: the boundary plus include/ekfvio_test_hooks.h (raw kernels,
+    in-kernel stamps, fault injection), for the tests and the profiling scripts only."""
+    from ekf_vio_amd import _build, capi
+    lib = capi.load(hooks=True)
+    hdr = open(os.path.join(ROOT, "include", "ekfvio_test_hooks.h")).read()
+    hooks = set(re.findall(r"\b(ekfvio_test_[a-z0-9_]+)\s*\(", hdr))
+    assert hooks and hooks == set(capi.HOOK_SYMBOLS), hooks ^ set(capi.HOOK_SYMBOLS)
+    for s in hooks:
+        assert hasattr(lib, s), s
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _build.HOOKS_LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (ekfvio_[a-z0-9_]+)", out))
+    assert exported == hooks | set(capi.SYMBOLS), exported ^ (hooks | set(capi.SYMBOLS))
+    assert "ekfvio_test" not in open(os.path.join(ROOT, "include", "ekfvio.h")).read()
 
 
 def test_default_config_matches_reference_params():
@@ -172,5 +189,21 @@ def test_chain_publication_wait_counts_the_loads_behind_the_stores():
     assert _build.check_counted_waits(good.replace("vmcnt(3)", "vmcnt(2)")) != []
     assert _build.check_counted_waits(good.replace("sc1\n", "sc1\n buffer_load_dword v9, v2, s[0:3], 0 offen\n", 1)) != []
     assert _build.check_counted_waits("nothing here") != []
+    # a kernel without ANY counted inline-asm wait must not pass (marker format changed, path restructured), and the
+    # store in front of the wait must be a write-through one
+    assert _build.check_counted_waits(good.replace("vmcnt(3)", "vmcnt(0)")) != []
+    assert _build.check_counted_waits(good.replace(";;#ASMSTART", ";;#SOMETHING")) != []
+    assert _build.check_counted_waits(good.replace(" offen sc1\n", " offen\n", 1)) != []
+    # a library whose ISA stamp is missing counts as stale: build() re-checks instead of trusting it
+    stamp = _build.ISA_STAMP
+    if os.path.exists(stamp) and os.path.exists(_build.LIB_PATH):
+        import fcntl
+        with open(os.path.join(_build.LIB_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            os.rename(stamp, stamp + ".moved")
+            try:
+                assert _build._stale()
+            finally:
+                os.rename(stamp + ".moved", stamp)
     _build.build()
     assert os.path.exists(_build.ISA_STAMP), "the shipped library was linked without the ISA check"

@@ -136,7 +136,7 @@ def test_gaussian_blur_before_fast_bit_exact(sigma, scale, crop):
     img = grey("640_480_test")
     if crop:
         img = np.ascontiguousarray(img[:crop[0], :crop[1]])
-    v = EKFVIO(max_features=80, fast_blur_sigma=sigma, inverse_image_scale=scale, fast_threshold=20)
+    v = EKFVIO(max_features=80, fast_blur_sigma=sigma, inverse_image_scale=scale, fast_threshold=20, hooks=True)  # (ekfvio_test_blurred_level0)
     assert v.addFrame(1.0, img, K) == capi.OK
     base = frame_resize(img, scale) if scale > 1 else img
     want = gaussian_blur5(base, sigma)

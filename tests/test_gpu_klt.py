@@ -52,7 +52,7 @@ def test_padded_levels_hold_reflect101_borders_whatever_the_buffers_held_before(
     borders (and, with the smaller pitch, everything else) come to lie; sizes that are no multiple of the 32-pixel tile,
     and levels narrower than two borders (several reflections)."""
     full = grey("640_480_test")
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     t = KLTTracker(g)
     for crop in [(480, 640), (251, 333), (97, 61), (120, 160), (23, 70), (480, 640)]:
         img = full[:crop[0], :crop[1]].copy()

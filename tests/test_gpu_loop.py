@@ -214,12 +214,11 @@ def test_frame_outputs_published_between_the_joseph_gemms_are_the_updated_state(
         od = v.odometry()
         assert np.array_equal(p3, od["position"]) and np.array_equal(q4, od["orientation_wxyz"])
         assert np.array_equal(l3, od["linear"]) and np.array_equal(a3, od["angular"])
-        n_early = C.c_int64(0)
-        assert v.tc_ekf.lib.ekfvio_test_early_output_frames(v.tc_ekf.h, C.byref(n_early)) == 0
+        n_early = v.tc_ekf.counters()["early_output_frames"]
         if mode == "1":
-            assert n_early.value >= 8, n_early.value  # (frames with all 48 landmarks alive; a lost landmark makes the next frame replenish)
+            assert n_early >= 8, n_early  # (frames with all 48 landmarks alive; a lost landmark makes the next frame replenish)
         else:
-            assert n_early.value == 0
+            assert n_early == 0
         runs[mode] = rows
         v.tc_ekf.close()
     for i, (a, b) in enumerate(zip(runs["1"], runs["0"])):

@@ -52,7 +52,7 @@ def maxabs(a, b):
 def test_gemm_against_fp64(M, N, K, tb, variant):
     if variant >= 32 and not tb:
         pytest.skip("the BM x 64 kernel is A * B^T only")
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K)).astype(np.float32)
     B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
@@ -72,7 +72,7 @@ def test_gemm_against_fp64(M, N, K, tb, variant):
 
 def test_gemm_is_an_ordered_fmaf_chain():
     """A = I with an asymmetric B catches a transposed C write; integers make it exact."""
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     n = 96
     B = (np.arange(n * n).reshape(n, n) % 17 - 5).astype(np.float32)
     C = g.test_gemm(np.eye(n, dtype=np.float32), B, np.zeros((n, n), np.float32), transB=False)
@@ -85,7 +85,7 @@ def test_gemm_is_an_ordered_fmaf_chain():
 
 @pytest.mark.parametrize("m,nr", [(2, 25), (64, 30), (130, 100), (512, 790), (1100, 70)])  # 1100: the split panel/update sweep
 def test_cholesky_and_right_solve(m, nr):
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     rng = np.random.default_rng(m)
     Q = rng.standard_normal((m, m))
     S = (Q @ Q.T / m + np.eye(m) * 0.1).astype(np.float32)
@@ -99,7 +99,7 @@ def test_cholesky_and_right_solve(m, nr):
 
 
 def test_cholesky_flags_non_positive_pivot():
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     S = np.eye(8, dtype=np.float32)
     S[3, 3] = -1.0
     _, _, info = g.test_cholesky_solve(S, np.ones((4, 8), np.float32))
@@ -113,7 +113,7 @@ def test_generated_pivot_chain_matches_plain_formulation_bits(monkeypatch):
     it (variants 8, 10, 12, 13) and with the plain readlane + fma formulation (variant 0): L and the 16x16 inverses must agree
     bit for bit (stamps[12], [13] are FNV-1a hashes of their bits)."""
     import ctypes as C
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     hashes = []
     for fv in ("0", "8", "10", "12", "13"):  # plain, generated chain, with its LDS loads/stores, rescheduled (12 = production)
         monkeypatch.setenv("EKFVIO_POTRF_FV", fv)
@@ -455,7 +455,7 @@ def test_persistent_sweep_matches_per_step_sweep(monkeypatch):
         res = []
         for mode in ("0", "1"):
             monkeypatch.setenv("EKFVIO_SWEEP", mode)
-            g = TightlyCoupledEKF(max_features=N)
+            g = TightlyCoupledEKF(max_features=N, hooks=True)
             L, X, info = g.test_cholesky_solve(S, Cr)
             assert info == 0
             g.addNewFeatures(sc.initial_features())
@@ -509,7 +509,7 @@ def test_indefinite_matrix_goes_through_the_signed_factorisation(m, npos, shuffl
     updates and into the gain.  Quasi-definite test matrix [[A, B], [B^T, -C]] (A, C positive definite: LDL^T exists for
     every symmetric permutation, with npos positive and m - npos negative pivots), optionally permuted so that the
     signs are mixed inside every 64-block; 1100 rows exercise the split sweep."""
-    g = TightlyCoupledEKF(max_features=4)
+    g = TightlyCoupledEKF(max_features=4, hooks=True)
     rng = np.random.default_rng(m + npos)
     def spd(k):
         Q = rng.standard_normal((k, k))
@@ -624,31 +624,51 @@ def test_persistent_per_tile_sweep_is_bit_identical_to_the_per_step_sweep(monkey
 
 
 @pytest.mark.parametrize("N,fails", [(544, 0), (700, 19)])
-def test_split_sweep_as_one_persistent_launch_is_bit_identical(monkeypatch, N, fails):
-    """The split sweep (16 block columns and more: panel blocks solved once and stored, chol_persist_la.inc) has two drivers for the same
-    tile tasks: one launch per block step (the default) and ONE persistent launch with a chain workgroup, a row worker per row block and
-    far-tile owners that hand results over through flags (EKFVIO_SWEEP_LA_PERSIST=1: measured, not faster, kept as an experiment --
-    profiles/r04_persistent_split_sweep_experiment.txt).  Every bit of the state must agree."""
+def test_split_sweep_forms_agree_bit_for_bit(monkeypatch, N, fails):
+    """The split sweep (16 block columns and more: panel blocks solved once and stored, chol_step_la.inc -- near column with its own panel
+    solve, far columns every second launch) against the plain two-launch form (panel launch + tile launch per block step,
+    EKFVIO_SWEEP_LA=0): every tile receives the same steps in the same order, so every bit of the state must agree.  (Round 4's third
+    driver, one persistent launch for the same tasks, was measured slower and left the product in round 5.)  EKFVIO_SWEEP_LA is read once
+    per process: the second form runs in a child process."""
+    import json, subprocess, sys, os
     sc = Scenario(N, seed=13)
     fr = list(sc.frames(3))
     for s, (z, R, p) in enumerate(fr):
         for q in range(fails):
             p[(7 * q + 3 * s + 1) % N] = 0
-    out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("EKFVIO_SWEEP_LA_PERSIST", mode)
-        g = TightlyCoupledEKF(max_features=N)
-        g.addNewFeatures(sc.initial_features())
-        for z, R, p in fr:
-            g.process(sc.dt)
-            assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
-        out[mode] = g.get_state()
-        assert (g.persistent_sweeps() > 0) == (mode == "1"), (mode, g.sweep_counts())
-        assert g.sweep_counts()["recoveries"] == 0
-        g.close()
-    assert np.isfinite(out["0"]["Sigma"]).all()
-    for k in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"):
-        assert np.array_equal(out["0"][k], out["1"][k]), k
+    g = TightlyCoupledEKF(max_features=N)
+    g.addNewFeatures(sc.initial_features())
+    for z, R, p in fr:
+        g.process(sc.dt)
+        assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
+    st = g.get_state()
+    assert g.persistent_sweeps() == 0
+    g.close()
+    assert np.isfinite(st["Sigma"]).all()
+    code = (
+        "import sys, numpy as np, hashlib\n"
+        "sys.path.insert(0, %r)\n"
+        "from ekf_vio_amd import TightlyCoupledEKF\n"
+        "from ekf_vio_amd.sim import Scenario\n"
+        "N, fails = %d, %d\n"
+        "sc = Scenario(N, seed=13)\n"
+        "fr = list(sc.frames(3))\n"
+        "for s, (z, R, p) in enumerate(fr):\n"
+        "    for q in range(fails):\n"
+        "        p[(7 * q + 3 * s + 1) %% N] = 0\n"
+        "g = TightlyCoupledEKF(max_features=N)\n"
+        "g.addNewFeatures(sc.initial_features())\n"
+        "for z, R, p in fr:\n"
+        "    g.process(sc.dt); g.updateWithFeaturePositions(z, R, p)\n"
+        "st = g.get_state()\n"
+        "print(' '.join(hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() for k in ('base_mu', 'feat_mu', 'Sigma', 'last_klt', 'del_flag')))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, fails)
+    env = dict(os.environ, EKFVIO_SWEEP_LA="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import hashlib
+    mine = " ".join(hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() for k in ("base_mu", "feat_mu", "Sigma", "last_klt", "del_flag"))
+    assert out.stdout.strip().splitlines()[-1] == mine
 
 
 @pytest.mark.parametrize("where", [(3,), (40,), (3, 40, 70, 120)])

@@ -9,7 +9,7 @@ TightlyCoupledEKF.cpp:577-580 always completes; it never hands a half-finished f
     the state is the per-step sweep's, bit for bit;
   * ekfvio_synchronize behind a device-resident run returns EKFVIO_EABORTED (distinct from EKFVIO_ENUMERIC);
   * the handle takes the per-step sweep from then on.
-The fault is injected through ekfvio_test_sweep_fault: a small spin limit and one owner workgroup that never raises its flag.
+The fault is injected through ekfvio_test_sweep_fault (include/ekfvio_test_hooks.h: the handles of these tests live in the hooks build): a small spin limit and one owner workgroup that never raises its flag.
 """
 import numpy as np
 import pytest
@@ -34,10 +34,10 @@ def _warm_state(N, steps=4):
     return sc, st, frames[steps:]
 
 
-@pytest.mark.parametrize("N,stall", [(256, 5), (256, 120), (128, 1), (544, 9)])
+@pytest.mark.parametrize("N,stall", [(256, 5), (256, 120), (128, 1)])
 def test_aborted_update_is_rerun_with_the_per_step_sweep_bit_for_bit(monkeypatch, N, stall):
-    """(N = 544: the split sweep's persistent form, an experiment behind EKFVIO_SWEEP_LA_PERSIST=1 -- chol_persist_la.inc; `stall` is then the row
-    worker that never publishes.)"""
+    """An owner workgroup of the persistent sweep never raises its tile's flag (fault injection): the waits give up, the Joseph GEMMs write
+    nothing, the host runs the update again with one launch per block step and latches the handle to that form."""
     sc, st, frames = _warm_state(N)
     z, R, p = frames[0]
     # the answer: the same step with one launch per block step from the start
@@ -54,10 +54,8 @@ def test_aborted_update_is_rerun_with_the_per_step_sweep_bit_for_bit(monkeypatch
     assert ref.sweep_counts()["persistent"] == 0
     ref.close()
     monkeypatch.delenv("EKFVIO_SWEEP")
-    if N >= 512:
-        monkeypatch.setenv("EKFVIO_SWEEP_LA_PERSIST", "1")
 
-    g = TightlyCoupledEKF(max_features=N)
+    g = TightlyCoupledEKF(max_features=N, hooks=True)
     g.set_state(st)
     g.process(sc.dt)
     predicted = g.get_state()
@@ -87,7 +85,7 @@ def test_aborted_device_resident_run_reports_eaborted_and_leaves_a_valid_state()
     z = np.stack([f[0] for f in frames]).astype(np.float32)
     R = np.stack([f[1] for f in frames]).astype(np.float32)
     p = np.stack([f[2] for f in frames]).astype(np.uint8)
-    g = TightlyCoupledEKF(max_features=N)
+    g = TightlyCoupledEKF(max_features=N, hooks=True)
     g.set_state(st)
     g.upload_measurements(z, R, p)
     g.sweep_fault(spin_limit=200, stall_workgroup=7)
@@ -118,7 +116,7 @@ def test_aborted_sweep_inside_the_image_loop_is_recovered():
     seq = translated_sequence(grey(), 5)
     out = {}
     for fault in (False, True):
-        v = EKFVIO(max_features=256, replenish=1, fast_threshold=20, min_new_feature_dist=12)
+        v = EKFVIO(max_features=256, replenish=1, fast_threshold=20, min_new_feature_dist=12, hooks=True)
         for i, img in enumerate(seq):
             if fault and i == 2:
                 v.tc_ekf.sweep_fault(spin_limit=200, stall_workgroup=9)
@@ -166,3 +164,41 @@ def test_symmetric_joseph_experiment_agrees_with_the_full_update_on_symmetric_in
     assert rel < 2e-5, rel
     assert np.abs(a["base_mu"] - b["base_mu"]).max() < 2e-6 and np.abs(a["feat_mu"] - b["feat_mu"]).max() < 2e-5
     assert np.array_equal(a["last_klt"], b["last_klt"]) and np.array_equal(a["del_flag"], b["del_flag"])
+
+
+def test_a_latched_handle_tries_the_persistent_sweep_again_later(monkeypatch):
+    """an abort latches the handle to one launch per block step; what kept the workgroups from being resident may be gone
+    later, so the persistent launch is tried again after a pause (2 s, doubling; EKFVIO_SWEEP_RETRY_S shortens the first one here).  The
+    retried update runs on zeroed flags and a zeroed abort word and gives the per-step sweep's bits."""
+    import time
+    N = 256
+    sc, st, frames = _warm_state(N)
+    monkeypatch.setenv("EKFVIO_SWEEP", "0")
+    ref = TightlyCoupledEKF(max_features=N)
+    ref.set_state(st)
+    want = []
+    for z, R, p in frames[:3]:
+        ref.process(sc.dt)
+        ref.updateWithFeaturePositions(z, R, p)
+        want.append(ref.get_state())
+    ref.close()
+    monkeypatch.delenv("EKFVIO_SWEEP")
+    monkeypatch.setenv("EKFVIO_SWEEP_RETRY_S", "0.2")
+    g = TightlyCoupledEKF(max_features=N, hooks=True)
+    g.set_state(st)
+    g.sweep_fault(spin_limit=200, stall_workgroup=7)
+    for i, (z, R, p) in enumerate(frames[:3]):
+        if i == 1:
+            c = g.sweep_counts()
+            assert c["mode"] == 0 and c["recoveries"] == 1, c   # latched by the first update's abort
+            g.sweep_fault(spin_limit=0, stall_workgroup=-1)      # the obstacle goes away ...
+        if i == 2:
+            time.sleep(0.3)                                      # ... and the pause passes
+        g.process(sc.dt)
+        assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
+        got = g.get_state()
+        for k in KEYS:
+            assert np.array_equal(got[k], want[i][k]), (i, k)
+    c = g.sweep_counts()
+    assert c["mode"] == 2 and c["persistent"] == 2 and c["recoveries"] == 1, c  # tried twice: aborted once, clean the second time
+    g.close()
