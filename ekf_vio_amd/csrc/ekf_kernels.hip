@@ -614,14 +614,20 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         }
         __syncthreads();
         PSTAMP_(3);
-        const int lf = tid / PT, lg = tid % PT;
+        // Lanes run along f, the ROW landmark: the 16 lanes of a group read / write 48 contiguous floats of a column of Sigma (three
+        // floats each, one 12-byte access), four columns groups per wavefront.  (Rounds 1-4 had the lanes along g: sixteen
+        // columns per access, 12 bytes apart in each -- 1.8 TB/s of the 8 n^2 bytes at N = 1024, where Sigma is 38 MB.)
+        const int lf = tid % PT, lg = tid / PT;
         const int f = f0 + lf, g = g0 + lg;
         if (f >= N || g >= N) return;
         float Pfg[3][3];  // own block P(22+3f+q, 22+3g+s)
 #pragma unroll
-        for (int sIdx = 0; sIdx < 3; sIdx++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) Pfg[q][sIdx] = P[(size_t)(EKF_BASE + 3 * g + sIdx) * ld + EKF_BASE + 3 * f + q];
+        for (int sIdx = 0; sIdx < 3; sIdx++) {
+            const float3 c3 = *reinterpret_cast<const float3*>(P + (size_t)(EKF_BASE + 3 * g + sIdx) * ld + EKF_BASE + 3 * f);
+            Pfg[0][sIdx] = c3.x;
+            Pfg[1][sIdx] = c3.y;
+            Pfg[2][sIdx] = c3.z;
+        }
         float Xg[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -635,7 +641,8 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
                 Xg[r][sIdx] = acc;
             }
 #pragma unroll
-        for (int sIdx = 0; sIdx < 3; sIdx++)
+        for (int sIdx = 0; sIdx < 3; sIdx++) {
+            float o3[3];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 float acc = 0.f;
@@ -644,8 +651,10 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
 #pragma unroll
                 for (int q = 0; q < 3; q++) acc = acc + Xg[r][q] * sDg[lg * 9 + q * 3 + sIdx];
                 const int i = EKF_BASE + 3 * f + r, j = EKF_BASE + 3 * g + sIdx;
-                Pout[(size_t)j * ld + i] = predict_finish(acc, i, j, dt);
+                o3[r] = predict_finish(acc, i, j, dt);
             }
+            *reinterpret_cast<float3*>(Pout + (size_t)(EKF_BASE + 3 * g + sIdx) * ld + EKF_BASE + 3 * f) = make_float3(o3[0], o3[1], o3[2]);
+        }
         PSTAMP_(4);
         return;
     }
