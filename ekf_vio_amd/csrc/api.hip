@@ -228,7 +228,11 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         hipDeviceProp_t prop;
         HIPC(f, hipGetDeviceProperties(&prop, device));
         f->num_cus = prop.multiProcessorCount;
-        const char* e = getenv("EKFVIO_SWEEP_RETRY_S");  // the first pause before a handle whose persistent sweep gave up tries it again (default 2 s)
+        const char* e = getenv("EKFVIO_EARLY_STATUS");  // 0: ekfvio_update publishes its status behind the update's last kernel (rounds 1-3)
+        if (e) f->early_status = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_UPLOAD_KERNEL");  // 0: the frame travels by the copy engine (hipMemcpyAsync) instead of the upload kernel
+        if (e) f->upload_kernel = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_SWEEP_RETRY_S");  // the first pause before a handle whose persistent sweep gave up tries it again (default 2 s)
         if (e && atof(e) > 0) f->sweep_retry_first_s = atof(e);
         e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
         if (e) f->sweep_mode = atoi(e) ? 2 : 0;
@@ -468,7 +472,7 @@ int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_
     // the host right behind the sweep, and the call returns while the two Joseph GEMMs are still running (everything the caller can do next
     // is ordered behind them on the handle's stream, or synchronises).  A step-by-step caller then keeps the GPU fed: the next step's
     // launches are in the queue before this step's last kernel ends (EKFVIO_EARLY_STATUS=0: publish behind the last kernel, as rounds 1-3).
-    static const bool early = getenv("EKFVIO_EARLY_STATUS") ? atoi(getenv("EKFVIO_EARLY_STATUS")) != 0 : true;
+    const bool early = f->early_status != 0;  // (per handle, read at create like every other knob: ADVICE r04)
     const int seq = next_status_seq(f);
     f->publish_after_sweep_seq = early ? seq : 0;
     launch_update(f, m, dz, dR, dp);

@@ -117,6 +117,8 @@ struct ekfvio_filter {
     int sweep_spin_limit = 0;         // > 0: looks per wait of the persistent sweep (test hook ekfvio_test_sweep_fault); 0: SWEEP_SPIN_LIMIT
     int sweep_stall_wg = -1;          // fault injection: this workgroup of the persistent launch never raises its flag
     const int* sweep_abort_word = nullptr;  // abort word of the persistent sweep enqueued last by launch_chol_sweep (null: another sweep)
+    int early_status = 1;              // EKFVIO_EARLY_STATUS: ekfvio_update returns behind the sweep, the Joseph GEMMs still running (api.hip)
+    int upload_kernel = 1;             // EKFVIO_UPLOAD_KERNEL: the frame's trip to device memory is a kernel reading mapped host memory (klt.hip)
     bool sweep_retry_armed = false;    // an aborted persistent sweep latched sweep_mode to 0: tried again at sweep_retry_at (api.hip, sweep_maybe_retry)
     double sweep_retry_pause_s = 0.0, sweep_retry_first_s = 2.0;
     std::chrono::steady_clock::time_point sweep_retry_at;

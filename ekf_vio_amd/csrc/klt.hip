@@ -1168,7 +1168,7 @@ static int push_frame_enqueue(ekfvio_filter* f, const uint8_t* image, int32_t wi
         for (int y = 0; y < height; y++) memcpy(f->h_image + (size_t)y * width, image + (size_t)y * stride, width);
     }
     hipStream_t st = f->stream;
-    static const int upload_kernel = getenv("EKFVIO_UPLOAD_KERNEL") ? atoi(getenv("EKFVIO_UPLOAD_KERNEL")) : 1;
+    const int upload_kernel = f->upload_kernel;  // (per handle, read at create)
     if (upload_kernel) {
         const int n16 = (int)(((size_t)width * height + 15) / 16);
         void* dsrc = nullptr;  // the device's address of the mapped buffer (the same pointer under unified addressing; asked for, not assumed)
@@ -1448,8 +1448,12 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
     if (bad & 2) {
         // The persistent sweep gave up (chol_persist.inc): the Joseph GEMMs wrote nothing, the state is the propagated one.
         // The update runs again now, with one launch per block step, over the landmarks it was enqueued for (the count is
-        // bumped below): idx, the measured coordinates per row, R and the row count are where the bookkeeping left them;
-        // rows and columns of landmarks the replenishment has added meanwhile lie outside n and are not touched.  (Those
+        // bumped below): idx, the measured coordinates per row, R and the row count are where the bookkeeping left them.
+        // Landmarks the replenishment has added meanwhile lie outside n, with ONE exception the re-run relies on an invariant for
+        // (ADVICE r04): the first Joseph GEMM writes n + 1 columns -- column n carries K y -- and the second zeroes rows 0 .. n-1 of
+        // column n again; column n is now the first new landmark's column.  addNewFeatures leaves a new landmark's cross-covariances
+        // exactly zero and its measurement-map entries at -1, so "zero before, K y in between, zero after" is what an update without
+        // new landmarks does to that padding column too (tests/test_gpu_sweep_abort.py, the replenishing-frame case).  (Those
         // landmarks were picked around the predicted, not the updated, landmark pixels: a valid state, not bit for bit the
         // frame an unshared GPU produces.)
         sweep_abort_latch(f);

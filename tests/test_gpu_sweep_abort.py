@@ -11,6 +11,8 @@ TightlyCoupledEKF.cpp:577-580 always completes; it never hands a half-finished f
   * the handle takes the per-step sweep from then on.
 The fault is injected through ekfvio_test_sweep_fault (include/ekfvio_test_hooks.h: the handles of these tests live in the hooks build): a small spin limit and one owner workgroup that never raises its flag.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -132,6 +134,42 @@ def test_aborted_sweep_inside_the_image_loop_is_recovered():
     # same tracker results; the states differ in rounding order only (persistent and per-step sweep are bit-identical, so in
     # fact they agree exactly unless the replenishment picked other landmarks on the recovered frame)
     assert np.abs(a["base_mu"] - b["base_mu"]).max() < 1e-3
+
+
+def test_abort_on_a_replenishing_frame_leaves_the_new_landmarks_alone(monkeypatch):
+    """ekfvio_step_image's abort recovery re-runs the update AFTER the replenishment has grown the state on the device.  The
+    re-run's first Joseph GEMM writes n + 1 columns (column n carries K y) and the second zeroes column n again -- and column n is by then
+    the first NEW landmark's column.  That is harmless because addNewFeatures leaves the new landmarks' cross-covariances exactly zero and
+    their measurement map entries at -1; the invariant checked here: after a recovered frame that added landmarks, every new landmark has
+    the prior on its diagonal block, zeros everywhere else in its rows and columns, and its initial mean."""
+    import time
+    from test_gpu_loop import K, grey
+    seq = translated_sequence(grey(), 6, dx=-4.0, dy=-2.0)  # new corners enter every frame
+    monkeypatch.setenv("EKFVIO_SWEEP_RETRY_S", "0.001")     # the handle finds its way back to the persistent sweep between frames
+    v = EKFVIO(max_features=256, replenish=1, fast_threshold=50, min_new_feature_dist=30, hooks=True)  # ~100 landmarks: room to add
+    hit = 0
+    for i, img in enumerate(seq):
+        n_before = v.tc_ekf.num_features
+        if i == 2:
+            v.tc_ekf.sweep_fault(spin_limit=200, stall_workgroup=5)   # every persistent sweep from here on aborts
+        time.sleep(0.1)                                               # (the retry pause doubles with every abort: 1, 2, 4, 8 ms)
+        rc = v.addFrame(1.0 + i / 30.0, img, K)
+        assert rc in (capi.OK, capi.ENUMERIC), (i, rc)
+        n_after = v.tc_ekf.num_features
+        if i >= 2 and n_after > n_before and v.tc_ekf.sweep_counts()["recoveries"] > hit:
+            hit = v.tc_ekf.sweep_counts()["recoveries"]
+            st = v.tc_ekf.get_state()
+            S = st["Sigma"]
+            for q in range(n_before, n_after):
+                rows = slice(22 + 3 * q, 25 + 3 * q)
+                blk = S[rows, rows].copy()
+                assert np.array_equal(np.diag(blk), np.array([1e-5, 1e-5, 100.0], np.float32)), (i, q, blk)
+                S2 = S.copy()
+                S2[rows, rows] = 0
+                assert not S2[rows, :].any() and not S2[:, rows].any(), (i, q)
+                assert st["feat_mu"][q, 2] == np.float32(2.0) and st["del_flag"][q] == 0
+    assert hit >= 1, "no recovered frame added landmarks: the case was not exercised"
+    v.tc_ekf.close()
 
 
 @pytest.mark.parametrize("N", [40, 256, 400])
