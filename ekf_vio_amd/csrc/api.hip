@@ -252,15 +252,12 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->persist_gain = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_PERSIST_EARLY");
         if (e) f->persist_early = atoi(e) ? 1 : 0;
-        e = getenv("EKFVIO_JOSEPH_SYM");  // experiment: 1 = only the lower triangle of the Joseph update's products, mirrored (common.h)
-        if (e) f->joseph_sym = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches
         if (e) f->fuse_linearize = atoi(e) ? 1 : 0;
     }
     HIPC(f, dev_alloc(f->stream, &f->Km, pm));
     HIPC(f, dev_alloc(f->stream, &f->Wt, pm));
     HIPC(f, dev_alloc(f->stream, &f->Gm, pm));
-    HIPC(f, dev_alloc(f->stream, &f->Kyp, (size_t)f->ldp * (f->m_cap / 64)));
     HIPC(f, dev_alloc(f->stream, &f->info, 4));
     HIPC(f, hipHostMalloc((void**)&f->h_info, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     memset(f->h_info, 0, 16 * sizeof(int));
@@ -322,7 +319,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     if (f->stream) (void)hipStreamSynchronize(f->stream);
     void* ptrs[] = {f->mu, f->mu_next, f->last_klt, f->del_flag, f->P,  f->P2, f->FA, f->FB, f->FD,   f->Fdense,
                     f->idx, f->inv_idx, f->zmeas,  f->Rmeas,    f->pass,     f->yres, f->Rm, f->Saug,  f->Laug,  f->Linv, f->Lsign, f->Km, f->sweep_sync, f->sweep_dbg,
-                    f->Wt,  f->Gm,     f->Kyp, f->info,     f->seq_z,    f->seq_R, f->seq_pass};
+                    f->Wt,  f->Gm,     f->info,     f->seq_z,    f->seq_R, f->seq_pass};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (f->h_info) hipHostFree(f->h_info);

@@ -1200,7 +1200,7 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.fused = 1, pa.gather_wgs = nb2;
     // the transposing workgroups stay and form the gain while the sweep runs, as long as (nearly) every workgroup of the launch finds a
     // compute unit at once: they hold theirs to the end
-    pa.gain = (f->persist_gain && !f->joseph_sym && gain_in_sweep_shape(f, m_pad, n_pad)) ? 1 : 0;
+    pa.gain = (f->persist_gain && gain_in_sweep_shape(f, m_pad, n_pad)) ? 1 : 0;
     pa.K = f->Km, pa.ldk = f->ldp;
     f->gain_in_sweep = pa.gain != 0;
     pa.dbg = f->sweep_dbg;

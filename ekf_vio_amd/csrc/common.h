@@ -143,10 +143,6 @@ struct ekfvio_filter {
     float* Km = nullptr;       // [ldp*m_cap]  Sigma H^T, solved in place into the Kalman gain
     float* Wt = nullptr;       // [ldp*m_cap]  (H Sigma)^T
     float* Gm = nullptr;       // [ldp*m_cap]  K R - T[:,idx]
-    float* Kyp = nullptr;      // [ldp*(m_cap/64)]  K y as partial sums per 64 measurement columns (gain GEMM, mode 4)
-    int joseph_sym = 0;        // 1 (EKFVIO_JOSEPH_SYM=1, experiment): only the lower triangle of T and Sigma' computed, and mirrored.  Measured in
-                               // round 4 and NOT adopted: taking the lower triangle of (I - K H) Sigma breaks the congruence the Joseph
-                               // form rests on -- more non-positive pivots from the raw prior, parity yardstick missed on asymmetric inputs
     int* info = nullptr;       // [4] device words: [0] non-positive pivot seen, [1] frame counter of uploaded sequences, [2] device-side m
     int* h_info = nullptr;     // pinned, device-mapped: [0] status word, [1] sequence number (publish_status_kernel)
     int* d_hinfo = nullptr;    // the device's address of h_info
@@ -226,16 +222,11 @@ struct ekfvio_filter {
 //          receives K*y.
 //  mode 2  Sigma' = T + G K^T: workgroup (0,0) also finishes the mean: mu += column n,
 //          quaternion renormalised (:600-609), column n zeroed again, frame counter advanced.
-//  mode 3  the same, K y taken from per-column-block partial sums (Schur flow, and the symmetric Joseph flow).
-//  mode 4  the gain GEMM K = Y L^-1 (pruned): every tile also leaves its share of K y = K (z - H mu) as a partial sum per
-//          64-column block (Kyp_out[block][state index]); mode 3 adds the blocks in order.
-//  sym     (modes 1-3) T = (I - K H) Sigma and Sigma' are symmetric in exact arithmetic (TightlyCoupledEKF.cpp:594-596, K the
-//          optimal gain): only the tiles that reach the lower triangle are computed, every element (i,j), i > j, is stored at
-//          (i,j) and at (j,i), and G gets both G(i, q(j)) and G(j, q(i)).  Half the tiles, half the MFMA work; Sigma comes out
-//          exactly symmetric where the reference's is symmetric to rounding (its fixSigma is a no-op, :716-718).
+//  mode 3  the same, K y taken from per-column-block partial sums (Schur flow).
+//  (Round 4's symmetric Joseph flow -- `sym`, and mode 4, the gain GEMM that left K y as partial sums for it -- was measured, rejected on parity
+//  and left the product in round 5: scripts/experiments/joseph_sym.txt, profiles/r04_symmetric_joseph_experiment.txt.)
 struct GemmEpi {
     int mode = 0;
-    int sym = 0;
     const int* inv_idx = nullptr;
     const float* Rm = nullptr;
     float* G = nullptr;
@@ -248,13 +239,6 @@ struct GemmEpi {
     int* frame_counter = nullptr;
     int frames = 0;
     long long* stamps = nullptr;  // diagnostic s_memtime stamps (library built with -DEKF_GEMM_STAMPS), per handle
-    // mode 4
-    const float* zrow = nullptr;  // measured coordinate per measurement row
-    const float* mu_in = nullptr; // the propagated mean
-    const int* idx = nullptr;     // state index per measurement row
-    int m = 0;                    // measurement rows (columns of K beyond it are padding)
-    const int* m_dev = nullptr;   // the same in device memory (ekfvio_step_image), or null
-    float* Kyp_out = nullptr;
     int* zero_words = nullptr;    // modes 2-3: the persistent sweep's flags, zeroed by workgroup (0,0) for the NEXT update's sweep
     int n_zero = 0;               // (everything but the abort word, which only ever goes up and retires the persistent path)
     const int* abort = nullptr;   // modes 1-3: abort word of the persistent sweep in front (non-zero: the factor is unfinished) --

@@ -1034,7 +1034,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         e1.G = f->Gm;
         e1.ldg = ld;
         e1.abort = e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: both GEMMs write nothing
-        if (!f->joseph_sym) {
+        {
             if (!f->gain_in_sweep) launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
             // The two P-update GEMMs, back to back (one profiler scope, two launches), both triangles:
             //   T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place; also G and K*y (column n)
@@ -1042,31 +1042,6 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)(n + 1) * m_pad + 2.0 * n * (double)n * m_pad, 2);
             launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
             if (f->between_joseph) f->between_joseph(f);  // (ekfvio_step_image: the frame's outputs, from mu and K y in column n of P)
-            launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
-        } else {
-            // The symmetric flow (round 4 experiment, EKFVIO_JOSEPH_SYM=1; measured and not adopted, see common.h and DESIGN.md).
-            // T = (I - K H) Sigma = Sigma - Sigma H^T S^-1 H Sigma and Sigma' = T (I - K H)^T + K R K^T
-            // are symmetric in exact arithmetic (:594-596 with the optimal gain): the tiles that reach the lower triangle are
-            // computed and mirrored -- half the tiles, so a smaller tile still fits one round of workgroups (N = 256: 176 tiles of
-            // 32 x 64 instead of 221 of 48 x 64).  K y no longer rides as an extra column of T (that column lies above the
-            // diagonal): the gain GEMM leaves it as partial sums per 64 measurement columns (mode 4), the last GEMM adds them.
-            GemmEpi e4;
-            e4.mode = 4;
-            e4.zrow = f->yres;
-            e4.mu_in = f->mu;
-            e4.idx = f->idx;
-            e4.m = m;
-            e4.m_dev = m_on_device ? f->info + 2 : nullptr;
-            e4.Kyp_out = f->Kyp;
-            e4.kyp_ld = ld;
-            launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0, &e4);
-            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad, 2);  // executed: half of 2 x 2 n n m_pad
-            e1.sym = e2.sym = 1;
-            e2.mode = 3;
-            e2.Kyp = f->Kyp;
-            e2.kyp_blocks = m_pad / 64;
-            e2.kyp_ld = ld;
-            launch_gemm(f, 1, n, n, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P, ld, 0, 0, &e1);
             launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P, ld, f->P, ld, 1, 0, &e2);
         }
     } else {
@@ -1094,12 +1069,8 @@ int launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
     e1.G = f->Gm;
     e1.ldg = ld;
     e2.mode = 2;  // n = 0: no mean update, no frame counter
-    if (f->joseph_sym) {
-        e1.sym = e2.sym = 1;
-        e2.mode = 3;
-    }
     for (int r = 0; r < reps; r++) {
-        launch_gemm(f, 1, n, f->joseph_sym ? n : n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P2, ld, 0, 0, &e1);
+        launch_gemm(f, 1, n, n + 1, m_pad, -1.f, f->Km, ld, f->Wt, ld, 1.f, f->P, ld, f->P2, ld, 0, 0, &e1);
         launch_gemm(f, 1, n, n, m_pad, 1.f, f->Gm, ld, f->Km, ld, 1.f, f->P2, ld, f->P2, ld, 1, 0, &e2);
     }
     return 2;

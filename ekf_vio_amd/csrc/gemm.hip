@@ -67,18 +67,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     const int wave = tid >> 6;
     const int wr = wave & 1;   // 32-row half of the tile
     const int wc = wave >> 1;  // 32-col half of the tile
-    int bx = blockIdx.x, by = blockIdx.y;
-    if ((EPI >= 1 && EPI <= 3) && epi.sym) {
-        // symmetric flow: a 1-D grid over the lower-triangle tiles, column by column from the diagonal down
-        const int T = (M + BM - 1) / BM;
-        int rem = blockIdx.x;
-        by = 0;
-        while (rem >= T - by) {
-            rem -= T - by;
-            by++;
-        }
-        bx = by + rem;
-    }
+    const int bx = blockIdx.x, by = blockIdx.y;
     const int i0 = bx * BM;
     const int j0 = by * BN;
 
@@ -204,18 +193,6 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
         }                                                                                      \
     } while (0)
 
-    // mode 4 (the gain GEMM): the innovation of this lane's sixteen measurement columns, for the tile's share of K y
-    float yv[16];
-    if (EPI == 4 && grp == 0) {
-        const int mm = epi.m_dev ? *epi.m_dev : epi.m;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int q = j0 + wc * 32 + 4 * lk + (r & 3) + 8 * (r >> 2);
-            const int qc = min(q, max(mm - 1, 0));
-            const float y = epi.zrow[qc] - epi.mu_in[epi.idx[qc]];  // z - H mu (:554-555)
-            yv[r] = (q < mm) ? y : 0.f;
-        }
-    }
     // The C tile this wave will update is requested first: vmcnt retires in order, so these
     // loads ride in front of the prologue's own round trip instead of stalling the first
     // staging wait of the K loop.
@@ -303,7 +280,6 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
         if (flush) v = (fabsf(v) > EKF_FLUSH_THRESH) ? v : 0.f;
         vout[r] = v;
     }
-    const bool sym = (EPI >= 1 && EPI <= 3) && epi.sym;
     if (EPI == 1) {
         // G(i,q) = (K R)(i,q) - T(i, idx[q]) for the measured columns of this tile (A is K).
         // All loads are unconditional on clamped indices (so they are issued as one batch);
@@ -327,45 +303,12 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
             const int j = j0 + wc * 32 + 4 * lk + (r & 3) + 8 * (r >> 2);
             const int q = qv[r];
             const float kr = ((q ^ 1) < q) ? (kp[r] + kq[r]) : (kq[r] + kp[r]);  // ascending measurement index
-            if (q >= 0 && j < N && i < M && (!sym || i >= j)) epi.G[(size_t)q * epi.ldg + i] = kr - vout[r];
+            if (q >= 0 && j < N && i < M) epi.G[(size_t)q * epi.ldg + i] = kr - vout[r];
         }
-        if (sym) {
-            // the mirror image: G(j, q(i)) = (K R)(j, q(i)) - T(j,i), T(j,i) := T(i,j), for the elements below the diagonal;
-            // q by the lane's row, the K entries of four consecutive columns as one 16-byte load
-            const int q = epi.inv_idx[ic];
-            if (q >= 0 && i < M) {
-                const float r0 = epi.Rm[2 * q], r1 = epi.Rm[2 * q + 1];
-#pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) {
-                    const int jb4 = j0 + wc * 32 + 4 * lk + 8 * c4;
-                    const float4 x = *reinterpret_cast<const float4*>(A + (size_t)q * lda + jb4);
-                    const float4 y = *reinterpret_cast<const float4*>(A + (size_t)(q ^ 1) * lda + jb4);
-                    const float xs[4] = {x.x * r0, x.y * r0, x.z * r0, x.w * r0}, ys[4] = {y.x * r1, y.y * r1, y.z * r1, y.w * r1};
-                    float* gp = epi.G + (size_t)q * epi.ldg + jb4;
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const float kr = ((q ^ 1) < q) ? (ys[v] + xs[v]) : (xs[v] + ys[v]);
-                        if (i > jb4 + v && jb4 + v < N) gp[v] = kr - vout[4 * c4 + v];
-                    }
-                }
-            }
-        }
-    }
-    if (EPI == 4) {
-        // this tile's share of K y in a fixed order: the lane's sixteen columns, then the four (column half, k half)
-        // partial sums of a row through LDS (the staging buffers are free: every wavefront is past the K loop)
-        float sy = vout[0] * yv[0];
-#pragma unroll
-        for (int r = 1; r < 16; r++) sy = sy + vout[r] * yv[r];
-        float* red = &BsG[0][0][0];
-        red[(wc * 2 + lk) * 64 + wr * 32 + li] = sy;
-        __syncthreads();
-        if (tid < 64 && i0 + tid < M)
-            epi.Kyp_out[(size_t)by * epi.kyp_ld + i0 + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
     }
     if ((EPI == 2 || EPI == 3) && bx == 0 && by == 0 && epi.n > 0) {
         // mu += K*y, quaternion renormalised.  EPI 2: K*y is column n of P, left there by the mode-1 GEMM; EPI 3 (Schur
-        // flow, symmetric flow): it arrives as per-column-block partial sums (joseph_g_kernel, the mode-4 gain GEMM), added here in block order
+        // flow): it arrives as per-column-block partial sums (joseph_g_kernel), added here in block order
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256 * GROUPS) {
             float v;
@@ -392,27 +335,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
         for (int e = threadIdx.x; e < epi.n_zero; e += 256 * GROUPS) epi.zero_words[e] = 0;  // the next update's sweep starts from zero flags
     }
     float* cp = C + (size_t)(j0 + wc * 32 + 4 * lk) * ldc + i;
-    if (sym) {
-        // lower triangle as computed, and its mirror image: element (i,j), i > j, also goes to (j,i); four consecutive
-        // columns of a lane are 16 contiguous bytes of column i
-        const bool below = bx > by && i0 + BM <= M;  // the whole tile lies strictly below the diagonal, inside the matrix
-        if (below) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = vout[r];
-#pragma unroll
-            for (int c4 = 0; c4 < 4; c4++)
-                *reinterpret_cast<float4*>(C + (size_t)i * ldc + j0 + wc * 32 + 4 * lk + 8 * c4) =
-                    make_float4(vout[4 * c4], vout[4 * c4 + 1], vout[4 * c4 + 2], vout[4 * c4 + 3]);
-        } else if (i < M) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int jo = (r & 3) + 8 * (r >> 2);
-                const int j = j0 + wc * 32 + 4 * lk + jo;
-                if (j < N && i >= j) cp[(size_t)jo * ldc] = vout[r];
-                if (j < N && i > j) C[(size_t)i * ldc + j] = vout[r];
-            }
-        }
-    } else if (i0 + BM <= M && j0 + BN <= N) {
+    if (i0 + BM <= M && j0 + BN <= N) {
 #pragma unroll
         for (int r = 0; r < 16; r++) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = vout[r];
     } else if (i < M) {
@@ -444,7 +367,7 @@ template <int BMt, int WPS, int EPI>
 __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float beta, const float* Cin,
                                                      int ldcin, float* C, int ldc, int flush, int lowerB, GemmEpi epi,
-                                                     int tiles_x, int tiles_y, int strip_w) {
+                                                     int tiles_x, int tiles_y) {
     constexpr int RB = BMt / 16;                            // 16-row blocks per wavefront
     constexpr int SA = (BMt % 32 == 16) ? BMt : BMt + 16;   // LDS row strides, both = 16 mod 32
     constexpr int SB = 80;
@@ -462,42 +385,12 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     const int nwg = gridDim.x;
     const int bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
     const int swz = xcd * bq + min(xcd, br) + (blockIdx.x >> 3);
-    // strip_w == 0 (production): the run goes down whole tile columns.  strip_w > 0 (EKFVIO_GEMM_STRIP, measured and not
-    // adopted): a compact 2-D patch instead -- strips of strip_w tile columns walked row by row, odd strips bottom-up.  At
-    // 790 x 790 x 512 that cuts the fabric-side traffic of a Joseph GEMM from 22.3 to 16.8 MB per launch (each XCD's L2
-    // fetches ~7 row panels of A and ~5 column panels of B instead of all 17 and 2-3) and the pair replayed back to back
-    // from 12.3 to 11.9 us, but inside the filter step the first Joseph GEMM gets SLOWER (12.76 -> 13.17 us by rocprofv3,
-    // step 120.3 -> 121.0 us, same box, three interleaved repetitions: profiles/r03_gemm_tile_order_experiment.txt): the
-    // operands were written by the previous kernel, every L2 is cold for them either way, and the whole-column runs are
-    // what leaves every L2 holding all of K for the second GEMM.
-    int ti, tj;
-    if (epi.sym) {
-        // lower-triangle tiles only, column by column: tile column tj holds the tile rows from (64 tj) / BMt down (the first
-        // whose last row reaches the diagonal); the XCD runs go down whole (shortened) tile columns as in the full grid
-        int rem = swz;
-        tj = 0;
-        for (;;) {
-            const int t0 = (64 * tj) / BMt;
-            const int cnt = tiles_x - t0;
-            if (rem < cnt || tj + 1 >= tiles_y) {
-                ti = t0 + rem;
-                break;
-            }
-            rem -= cnt;
-            tj++;
-        }
-    } else if (strip_w <= 0) {
-        ti = swz % tiles_x;
-        tj = swz / tiles_x;
-    } else {
-        const int per = tiles_x * strip_w;
-        const int sidx = swz / per;
-        const int rem = swz - sidx * per;
-        const int w = min(strip_w, tiles_y - sidx * strip_w);
-        const int rr = rem / w;
-        ti = (sidx & 1) ? tiles_x - 1 - rr : rr;
-        tj = sidx * strip_w + (rem - rr * w);
-    }
+    // The run goes down whole tile columns.  (A compact 2-D patch per XCD -- strips of a few tile columns walked row by row -- cuts the
+    // fabric-side traffic of a Joseph GEMM at 790 x 790 x 512 from 22.3 to 16.8 MB per launch and the pair replayed back to back from
+    // 12.3 to 11.9 us, but inside the filter step the first Joseph GEMM gets SLOWER (12.76 -> 13.17 us, step 120.3 -> 121.0 us:
+    // profiles/r03_gemm_tile_order_experiment.txt): the operands were written by the previous kernel, every L2 is cold for them either
+    // way, and the whole-column runs are what leaves every L2 holding all of K for the second GEMM.  Removed in round 5.)
+    const int ti = swz % tiles_x, tj = swz / tiles_x;
     const int i0 = ti * BMt;
     const int j0 = tj * 64;
 
@@ -566,36 +459,6 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
                 kq[a][v] = A[(size_t)q * lda + ic] * epi.Rm[2 * q];
                 kp[a][v] = A[(size_t)(q ^ 1) * lda + ic] * epi.Rm[2 * q + 1];
             }
-        }
-    }
-    // symmetric flow (epi.sym): the mirror image needs G(j, q(i)) = (K R)(j, q(i)) - T(i,j) as well: q by the lane's ROW, the
-    // K entries of the four columns jb .. jb+3 as one 16-byte load each
-    int qm[RB];
-    float4 kmq[RB], kmp[RB];
-    if (EPI == 1 && kg == 0 && epi.sym) {
-        const int jbq = min(j0 + 16 * wave + 4 * g, Mread - 4);
-#pragma unroll
-        for (int a = 0; a < RB; a++) qm[a] = epi.inv_idx[min(i0 + 16 * a + li, M - 1)];
-#pragma unroll
-        for (int a = 0; a < RB; a++) {
-            const int q = max(qm[a], 0);
-            const float r0 = epi.Rm[2 * q], r1 = epi.Rm[2 * q + 1];
-            const float4 x = *reinterpret_cast<const float4*>(A + (size_t)q * lda + jbq);
-            const float4 y = *reinterpret_cast<const float4*>(A + (size_t)(q ^ 1) * lda + jbq);
-            kmq[a] = make_float4(x.x * r0, x.y * r0, x.z * r0, x.w * r0);
-            kmp[a] = make_float4(y.x * r1, y.y * r1, y.z * r1, y.w * r1);
-        }
-    }
-    // mode 4 (the gain GEMM): the innovation of this lane's four measurement columns, for the tile's share of K y
-    float yv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == 4 && kg == 0) {
-        const int mm = epi.m_dev ? *epi.m_dev : epi.m;
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int q = j0 + 16 * wave + 4 * g + v;
-            const int qc = min(q, max(mm - 1, 0));
-            const float y = epi.zrow[qc] - epi.mu_in[epi.idx[qc]];  // z - H mu (:554-555)
-            yv[v] = (q < mm) ? y : 0.f;
         }
     }
     // Three staging register sets, X, Y and Z, rotate between iterations (tile t+1 sits in one, tile t+2 is in
@@ -791,7 +654,6 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             vout[a][v] = x;
         }
     const int jb = j0 + 16 * wave + 4 * g;
-    const bool sym = (EPI >= 1 && EPI <= 3) && epi.sym;
     if (EPI == 1) {
         // G(i,q) = (K R)(i,q) - T(i, idx[q]) for the measured columns of this tile (A is K)
 #pragma unroll
@@ -801,54 +663,13 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             for (int v = 0; v < 4; v++) {
                 const int q = qv[v];
                 const float kr = ((q ^ 1) < q) ? (kp[a][v] + kq[a][v]) : (kq[a][v] + kp[a][v]);  // ascending measurement index
-                if (q >= 0 && jb + v < N && i < M && (!sym || i >= jb + v)) epi.G[(size_t)q * epi.ldg + i] = kr - vout[a][v];
+                if (q >= 0 && jb + v < N && i < M) epi.G[(size_t)q * epi.ldg + i] = kr - vout[a][v];
             }
-        }
-        if (sym) {  // the mirror image: G(j, q(i)) = (K R)(j, q(i)) - T(j,i), T(j,i) := T(i,j), for the elements below the diagonal
-#pragma unroll
-            for (int a = 0; a < RB; a++) {
-                const int i = i0 + 16 * a + li;
-                const int q = qm[a];
-                if (q < 0 || i >= M) continue;
-                const float kqv[4] = {kmq[a].x, kmq[a].y, kmq[a].z, kmq[a].w}, kpv[4] = {kmp[a].x, kmp[a].y, kmp[a].z, kmp[a].w};
-                float gv[4];
-#pragma unroll
-                for (int v = 0; v < 4; v++) gv[v] = (((q ^ 1) < q) ? (kpv[v] + kqv[v]) : (kqv[v] + kpv[v])) - vout[a][v];
-                float* gp = epi.G + (size_t)q * epi.ldg + jb;
-                if (i > jb + 3 && jb + 3 < N) {
-                    *reinterpret_cast<float4*>(gp) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 4; v++)
-                        if (i > jb + v && jb + v < N) gp[v] = gv[v];
-                }
-            }
-        }
-    }
-    if (EPI == 4) {
-        // this tile's share of K y, summed in a fixed order: the lane's four columns, then the sixteen (wavefront, lane
-        // group) partial sums of a row through LDS (the staging buffers are free: every wavefront is past the K loop)
-        float* red = &Bs[0][0];
-#pragma unroll
-        for (int a = 0; a < RB; a++) {
-            float sy = vout[a][0] * yv[0];
-            sy = sy + vout[a][1] * yv[1];
-            sy = sy + vout[a][2] * yv[2];
-            sy = sy + vout[a][3] * yv[3];
-            red[(wave * 4 + g) * BMt + 16 * a + li] = sy;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();        // (WPS = 2: the other wavefronts have returned)
-        if (tid < BMt && i0 + tid < M) {
-            float sy = red[tid];
-#pragma unroll
-            for (int e = 1; e < 16; e++) sy = sy + red[e * BMt + tid];
-            epi.Kyp_out[(size_t)tj * epi.kyp_ld + i0 + tid] = sy;
         }
     }
     if ((EPI == 2 || EPI == 3) && i0 == 0 && j0 == 0 && epi.n > 0) {
         // mu += K*y, quaternion renormalised.  EPI 2: K*y is column n of P, left there by the mode-1 GEMM; EPI 3 (Schur
-        // flow, symmetric flow): it arrives as per-column-block partial sums (joseph_g_kernel, the mode-4 gain GEMM), added here in block order
+        // flow): it arrives as per-column-block partial sums (joseph_g_kernel), added here in block order
         __shared__ float s_q[4];
         for (int e = threadIdx.x; e < epi.n; e += 256) {
             float v;
@@ -876,27 +697,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
         for (int e = threadIdx.x; e < epi.n_zero; e += 256) epi.zero_words[e] = 0;  // the next update's sweep starts from zero flags
     }
     float* cp = C + (size_t)jb * ldc + i0 + li;
-    if (sym) {
-        // lower triangle as computed, and its mirror image: element (i,j), i > j, also goes to (j,i) -- the lane's four
-        // columns jb .. jb+3 are 16 contiguous bytes of row... of COLUMN i of C
-        const bool below = i0 >= j0 + 64 && i0 + BMt <= M;  // the whole tile lies strictly below the diagonal, inside the matrix
-#pragma unroll
-        for (int a = 0; a < RB; a++) {
-            const int i = i0 + 16 * a + li;
-            if (below) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) cp[(size_t)v * ldc + 16 * a] = vout[a][v];
-                *reinterpret_cast<float4*>(C + (size_t)i * ldc + jb) = make_float4(vout[a][0], vout[a][1], vout[a][2], vout[a][3]);
-            } else if (i < M) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int j = jb + v;
-                    if (j < N && i >= j) cp[(size_t)v * ldc + 16 * a] = vout[a][v];
-                    if (j < N && i > j) C[(size_t)i * ldc + j] = vout[a][v];
-                }
-            }
-        }
-    } else if (i0 + BMt <= M && j0 + 64 <= N) {  // interior tile: no per-element tests
+    if (i0 + BMt <= M && j0 + 64 <= N) {  // interior tile: no per-element tests
 #pragma unroll
         for (int a = 0; a < RB; a++)
 #pragma unroll
@@ -914,42 +715,6 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     GSTAMP(38);
 }
 
-// EKFVIO_GEMM_STRIP=<w> (diagnostic): gemm16_kernel's tile order in strips of w tile columns; -1 picks the width that
-// minimises the operand panels the eight XCD L2s fetch between them, counted as the kernel assigns tiles.  Unset / 0:
-// the production order (see the kernel).
-static int xcd_strip_width(int tx, int ty, int bm) {
-    static const int forced = getenv("EKFVIO_GEMM_STRIP") ? atoi(getenv("EKFVIO_GEMM_STRIP")) : 0;
-    if (forced == 0) return 0;
-    if (forced > 0) return forced < ty ? forced : ty;
-    const int nwg = tx * ty, bq = nwg >> 3, br = nwg & 7;
-    long best = -1;
-    int best_w = ty;
-    std::vector<unsigned char> rows(tx), cols(ty);
-    for (int w = 1; w <= ty; w++) {
-        long cost = 0;
-        int pos = 0;
-        for (int x = 0; x < 8; x++) {
-            const int cnt = bq + (x < br ? 1 : 0);
-            std::fill(rows.begin(), rows.end(), 0);
-            std::fill(cols.begin(), cols.end(), 0);
-            for (int q = pos; q < pos + cnt; q++) {
-                const int per = tx * w, sidx = q / per, rem = q - sidx * per;
-                const int ww = std::min(w, ty - sidx * w), rr = rem / ww;
-                rows[(sidx & 1) ? tx - 1 - rr : rr] = 1;
-                cols[sidx * w + (rem - rr * ww)] = 1;
-            }
-            pos += cnt;
-            for (int r = 0; r < tx; r++) cost += rows[r] ? bm : 0;
-            for (int c = 0; c < ty; c++) cost += cols[c] ? 64 : 0;
-        }
-        if (best < 0 || cost < best) {
-            best = cost;
-            best_w = w;
-        }
-    }
-    return best_w;
-}
-
 // cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
 // (512 threads); +100 = the same with 256 threads
 static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -962,16 +727,7 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
     e.stamps = f->gemm_stamps;
     const int cus = f->num_cus > 0 ? f->num_cus : 256;  // per handle: handles on different devices may differ
     const int ty = (N + 63) / 64;
-    const bool sym = e.sym && e.mode >= 1 && e.mode <= 3 && M == N;
-    e.sym = sym ? 1 : 0;
-    // tiles of a bm x 64 tiling: all of them, or (symmetric flow) those that reach the lower triangle
-    auto tiles = [&](int bm) {
-        const int tx = (M + bm - 1) / bm;
-        if (!sym) return tx * ty;
-        int c = 0;
-        for (int tj = 0; tj < ty; tj++) c += tx - (64 * tj) / bm;
-        return c;
-    };
+    auto tiles = [&](int bm) { return ((M + bm - 1) / bm) * ty; };
     if (cfg == 0) {
         cfg = 1;
         if (transB && K % 64 == 0) {
@@ -989,10 +745,9 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         const int bm = cfg % 100;
         const int tx = (M + bm - 1) / bm;
         dim3 grid(tiles(bm));
-        const int sw = xcd_strip_width(tx, ty, bm);
 #define GEMM16_GO(BMv, W, EP)                                                                                           \
     hipLaunchKernelGGL((gemm16_kernel<BMv, W, EP>), grid, dim3(256 * W), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, \
-                       ldc, flush, lowerB, e, tx, ty, sw)
+                       ldc, flush, lowerB, e, tx, ty)
 #define GEMM16_BM(W, EP)                          \
     do {                                          \
         if (bm == 32) GEMM16_GO(32, W, EP);       \
@@ -1002,7 +757,6 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         if (e.mode == 1) GEMM16_BM(2, 1);
         else if (e.mode == 2) GEMM16_BM(2, 2);
         else if (e.mode == 3) GEMM16_BM(2, 3);
-        else if (e.mode == 4) GEMM16_BM(2, 4);
         else if (wps == 2) GEMM16_BM(2, 0);
         else GEMM16_BM(1, 0);
 #undef GEMM16_BM
@@ -1011,7 +765,6 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
     }
     const int groups = cfg == 2 ? 2 : 1;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    if (sym) grid = dim3(grid.x * (grid.x + 1) / 2, 1);  // lower-triangle tiles, 1-D (see the kernel)
 #define GEMM_GO(TB, G, EP)                                                                                             \
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G, EP>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
                        Cin, ldcin, C, ldc, flush, lowerB, e)
@@ -1021,8 +774,6 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         GEMM_GO(true, 1, 2);
     } else if (e.mode == 3) {
         GEMM_GO(true, 1, 3);
-    } else if (e.mode == 4) {
-        GEMM_GO(true, 1, 4);
     } else if (groups == 2) {
         if (transB) GEMM_GO(true, 2, 0);
         else GEMM_GO(false, 2, 0);
