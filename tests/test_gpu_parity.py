@@ -178,6 +178,34 @@ def test_jacobian_scenarios_bit_exact():
     g.close()
 
 
+def test_process_follows_the_sse2_eigen_build_on_a_rotated_state():
+    """at q = identity (the reference's own Jacobian test) most products of the quaternion multiplication are exact
+    zeros and every summation order gives the same bits; on a rotated, moving state the x86-64 SSE2 Eigen build and the generic one
+    differ (tests/_variants.py, profiles/r05_oracle_variant_spread.txt: up to 3e-5 in F).  The HIP path follows the SSE2 order -- the
+    build the reference's CMake flags produce -- bit for bit, and the test shows the other order is NOT what it computes."""
+    from _variants import DEFAULT, jacobian_case
+    uv = np.array(UV3 * 4, np.float32)
+    g = TightlyCoupledEKF(max_features=16)
+    g.addNewFeatures(uv)
+    o = OracleFilter(np.float32, emulate_static_cache=False, **DEFAULT)
+    o.add_new_features(uv)
+    st = o.get_state()
+    q = np.array([0.61, -0.37, 0.52, 0.47])
+    st["base_mu"][3:7] = (q / np.linalg.norm(q)).astype(np.float32)
+    st["base_mu"][0:3], st["base_mu"][7:10] = (0.3, -1.2, 0.7), (0.4, -0.3, 0.9)
+    st["base_mu"][10:13], st["base_mu"][13:16] = (0.31, -0.23, 0.52), (0.8, 0.1, -0.6)
+    o.set_state(st), g.set_state(st)
+    F_hip = g.numericallyLinearizeProcess(0.1)
+    assert np.array_equal(F_hip, o.linearize(0.1))
+    F_generic = jacobian_case(4, 0.1, dict(eigen_sse_quat=0, trig_float=0, div_reciprocal=0), generic=True)
+    assert F_generic.shape == F_hip.shape and not np.array_equal(F_hip, F_generic)
+    g.process(0.1), o.process(0.1)
+    sg, so = g.get_state(), o.get_state()
+    for k in ("base_mu", "feat_mu", "Sigma"):
+        assert np.array_equal(sg[k], so[k]), k
+    g.close(), o.close()
+
+
 def test_motion_model_golden_scenarios():
     """test/test_ekf.cpp:154-204 inputs; expected values tests/golden/kat.json (fp64-derived)."""
     g = TightlyCoupledEKF(max_features=4)
