@@ -40,3 +40,5 @@ for j in range(2, mb - 1):
     if v[b] and v[b + 7]:
         print("staged last step of tile (%d,%d): " % (j + 1, j) + "  ".join("%s %5d" % (sn[q], v[b + q + 1] - v[b + q]) for q in range(7)))
 print("wavefront 0's early look at the step's two flags (100 = both up, 101 = not yet):", [int(v[500 + k]) for k in range(1, mb - 1)])
+print("slack of the chain's look at step k's end (for tiles (k+2,k+1) / (k+2,k+2)) behind their owners' publish, cycles at 2.4 GHz (100 MHz clock: +-24):")
+print([(int((v[700 + k] - v[720 + k + 1]) * 24) if v[720 + k + 1] else None, int((v[700 + k] - v[740 + k + 2]) * 24) if v[740 + k + 2] else None) for k in range(mb - 2)])
