@@ -514,7 +514,7 @@ def main():
                              "shape": {"M": n, "N": n, "K": m_pad}}
         # HBM-side traffic and MFMA-busy counters of the same kernels come from separate rocprofv3 --pmc passes
         # (bench.py cannot collect PMCs itself); the committed summaries are quoted when the workload matches
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_n256.json" % tag)
             if N == 256 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
@@ -524,7 +524,7 @@ def main():
                     extra["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)" % tag
                     extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
                     break
-        for tag in ("r04", "r03", "r02"):
+        for tag in ("r05", "r04", "r03", "r02"):
             mf = os.path.join(ROOT, "profiles", "%s_pmc_mfma_n256.json" % tag)
             if N == 256 and os.path.exists(mf):
                 mj = json.load(open(mf))

@@ -67,7 +67,23 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     const int wave = tid >> 6;
     const int wr = wave & 1;   // 32-row half of the tile
     const int wc = wave >> 1;  // 32-col half of the tile
-    const int bx = blockIdx.x, by = blockIdx.y;
+    // Tile order.  Workgroups are dealt round-robin to the eight XCDs by their linear index x + y * gridDim.x: with the tiles in that order every
+    // XCD's L2 sees every operand panel of the product, and a Joseph GEMM at N = 1024 (49 x 49 tiles, K = 2048) pulls 1.5 GB per launch
+    // through the fabric for 127 MB of operands (profiles/r05_pmc_traffic_n1024.json).  order2d (round 5): XCD x takes the x-th run of
+    // ceil(T / 8) tiles of an order that walks strips of ceil(tiles_n / 8) tile columns row by row, so the ~96 tiles an XCD has in flight share
+    // ~14 row panels and ~7 column panels.  A permutation of which workgroup forms which tile: the same bits.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (epi.order2d) {
+        const int tm = gridDim.x, tn = gridDim.y, T = tm * tn;
+        const int L = (int)blockIdx.x + (int)blockIdx.y * tm;
+        const int bq = T >> 3, br = T & 7, xcd = L & 7;
+        const int swz = xcd * bq + min(xcd, br) + (L >> 3);
+        const int W = (tn + 7) >> 3, per = tm * W;
+        const int st = swz / per, within = swz - st * per;
+        const int wcs = min(W, tn - st * W);
+        bx = within / wcs;
+        by = st * W + within - bx * wcs;
+    }
     const int i0 = bx * BM;
     const int j0 = by * BN;
 
@@ -765,6 +781,9 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
     }
     const int groups = cfg == 2 ? 2 : 1;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    // throughput regime (several tiles per compute unit and a full contraction per tile): compact 2-D patches per XCD.  Not for the
+    // triangular-aware gain GEMM: its tiles' work falls with the tile column, and strips of columns would load the XCDs unevenly.
+    e.order2d = (f->gemm_order2d && !lowerB && (int)(grid.x * grid.y) >= 2 * cus) ? 1 : 0;
 #define GEMM_GO(TB, G, EP)                                                                                             \
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G, EP>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
                        Cin, ldcin, C, ldc, flush, lowerB, e)
