@@ -592,7 +592,7 @@ def main():
                                        "frac": (fl["cholesky_sweep"] + fl["gain_gemm"]) / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                        "note": "event-bracketed stage time of the eager, per-stage timed run (includes a few us of launch gaps); "
                                                "since round 4 the stage is ONE launch that also holds the measurement gather, the first diagonal tile and the gain's tiles "
-                                               "(chol_persist_kernel, fused); in-kernel stamps: profiles/r04_cholesky_phase_stamps.txt"}
+                                               "(chol_persist_kernel, fused); in-kernel stamps: profiles/r05_cholesky_phase_stamps.txt"}
     g.close()
     if rank == 0 and world == 1 and not args.no_full_loop:
         try:
