@@ -70,6 +70,30 @@ def test_gemm_against_fp64(M, N, K, tb, variant):
     g.close()
 
 
+@pytest.mark.parametrize("M,N,tb", [(2100, 1050, True), (1050, 2100, True), (2600, 830, False), (1601, 1409, True)])
+def test_throughput_regime_gemm_tile_order_is_a_permutation(monkeypatch, M, N, tb):
+    """Round 5: with two or more tiles per compute unit gemm_f32_mfma_kernel gives each XCD a compact 2-D patch of tiles (strips of
+    ceil(tiles_n / 8) tile columns walked row by row, GemmEpi::order2d).  Which workgroup forms which tile must not show in the result:
+    ragged shapes whose tile counts and strip widths do not divide evenly (33 x 17, 17 x 33, 41 x 13, 26 x 23 tiles) against the
+    block-index order, bit for bit, and against fp64."""
+    K = 32
+    rng = np.random.default_rng(M + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    out = {}
+    for order in ("1", "0"):
+        monkeypatch.setenv("EKFVIO_GEMM_ORDER2D", order)  # (read when the handle is created)
+        g = TightlyCoupledEKF(max_features=4, hooks=True)
+        out[order] = g.test_gemm(A, B, C0, alpha=-1.0, beta=1.0, transB=tb, variant=1)
+        g.close()
+    assert np.array_equal(out["1"], out["0"])
+    Bm = (B.T if tb else B).astype(np.float64)
+    ref = C0.astype(np.float64) - A.astype(np.float64) @ Bm
+    bound = (K + 4) * 6e-8 * (np.abs(A).astype(np.float64) @ np.abs(Bm) + np.abs(C0))
+    assert np.all(np.abs(out["1"] - ref) <= bound)
+
+
 def test_gemm_is_an_ordered_fmaf_chain():
     """A = I with an asymmetric B catches a transposed C write; integers make it exact."""
     g = TightlyCoupledEKF(max_features=4, hooks=True)
