@@ -609,6 +609,13 @@ def main():
                 extra["config3_n1024"] = device_resident_rate(1024, local, steps=30, warm=6, with_roofline=True)
                 extra["predict_dense"] = device_resident_rate(N, local, steps=100, predict="dense")
                 extra["predict_dense"]["structured_steps_per_s_same_run"] = world * args.steps / elapsed
+                # the sweep as one launch per block step (EKFVIO_SWEEP=0: what a node that shares its GPU runs, what several handles on one
+                # device run, and what an aborted persistent launch is rerun with); the switch is read when the handle is created
+                os.environ["EKFVIO_SWEEP"] = "0"
+                try:
+                    extra["per_step_sweep_n256"] = device_resident_rate(N, local)
+                finally:
+                    del os.environ["EKFVIO_SWEEP"]
             except Exception as ex:
                 extra["other_sizes"] = {"error": repr(ex)}
             try:
