@@ -611,11 +611,15 @@ def main():
                 extra["predict_dense"]["structured_steps_per_s_same_run"] = world * args.steps / elapsed
                 # the sweep as one launch per block step (EKFVIO_SWEEP=0: what a node that shares its GPU runs, what several handles on one
                 # device run, and what an aborted persistent launch is rerun with); the switch is read when the handle is created
+                prev_sweep = os.environ.get("EKFVIO_SWEEP")
                 os.environ["EKFVIO_SWEEP"] = "0"
                 try:
                     extra["per_step_sweep_n256"] = device_resident_rate(N, local)
                 finally:
-                    del os.environ["EKFVIO_SWEEP"]
+                    if prev_sweep is None:
+                        del os.environ["EKFVIO_SWEEP"]
+                    else:
+                        os.environ["EKFVIO_SWEEP"] = prev_sweep
             except Exception as ex:
                 extra["other_sizes"] = {"error": repr(ex)}
             try:
