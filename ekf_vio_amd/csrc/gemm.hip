@@ -379,6 +379,39 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
 // t+2 are issued at the top of tile t.
 // Workgroups are dealt round-robin to the 8 XCDs; the 1-D block index is remapped so that every
 // XCD works on a contiguous run of tiles and re-reads the same operand panels from ITS L2.
+// The end of the update that is nobody's tile (round 5: was done by the workgroup of tile (0,0) in front of its tile's store, which made that
+// workgroup the launch's last by a memory round trip; now by one more workgroup behind the tiles' -- 221 tiles leave 35 compute units idle at
+// N = 256): mu += K*y, quaternion renormalised (EPI 2: K*y is column n of P, left there by the mode-1 GEMM; EPI 3, the Schur flow: per-column-block
+// partial sums of joseph_g_kernel, added in block order), the device frame counter, and the next update's sweep flags zeroed.  256 threads.
+template <int EPI>
+__device__ __forceinline__ void gemm16_finish_mean(const GemmEpi& epi) {
+    __shared__ float s_q[4];
+    for (int e = threadIdx.x; e < epi.n; e += 256) {
+        float v;
+        if (EPI == 3) {
+            float ky = epi.Kyp[e];
+            for (int cb = 1; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
+            v = epi.mu[e] + ky;
+        } else {
+            v = epi.mu[e] + epi.Pcol[e];
+            epi.Pcol[e] = 0.f;
+        }
+        if (e >= 3 && e <= 6) s_q[e - 3] = v;
+        else epi.mu[e] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): s_q written
+    __builtin_amdgcn_s_barrier();        // (the workgroup's other wavefronts have returned)
+    if (threadIdx.x < 4) {
+        const float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
+        epi.mu[3 + threadIdx.x] = s_q[threadIdx.x] / qn;
+    }
+    if (threadIdx.x == 0 && epi.frame_counter) {
+        const int fi = *epi.frame_counter + 1;
+        *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
+    }
+    for (int e = threadIdx.x; e < epi.n_zero; e += 256) epi.zero_words[e] = 0;  // the next update's sweep starts from zero flags
+}
+
 template <int BMt, int WPS, int EPI>
 __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float beta, const float* Cin,
@@ -397,8 +430,16 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     __shared__ __attribute__((aligned(16))) float As[3][BKK * SA];
     __shared__ __attribute__((aligned(16))) float Bs[3][BKK * SB];
 
+    // (EPI 2 / 3 with a mean to finish: one workgroup more than tiles)
+    if ((EPI == 2 || EPI == 3) && (int)blockIdx.x == tiles_x * tiles_y) {
+        if (threadIdx.x >= 256) return;
+        int aborted = 0;
+        if (epi.abort) aborted = *epi.abort;  // (an aborted persistent sweep in front: this update writes nothing)
+        if (!aborted && epi.n > 0) gemm16_finish_mean<EPI>(epi);
+        return;
+    }
     // XCD-aware tile order (bijective for any grid size)
-    const int nwg = gridDim.x;
+    const int nwg = tiles_x * tiles_y;
     const int bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
     const int swz = xcd * bq + min(xcd, br) + (blockIdx.x >> 3);
     // The run goes down whole tile columns.  (A compact 2-D patch per XCD -- strips of a few tile columns walked row by row -- cuts the
@@ -683,35 +724,6 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
             }
         }
     }
-    if ((EPI == 2 || EPI == 3) && i0 == 0 && j0 == 0 && epi.n > 0) {
-        // mu += K*y, quaternion renormalised.  EPI 2: K*y is column n of P, left there by the mode-1 GEMM; EPI 3 (Schur
-        // flow): it arrives as per-column-block partial sums (joseph_g_kernel), added here in block order
-        __shared__ float s_q[4];
-        for (int e = threadIdx.x; e < epi.n; e += 256) {
-            float v;
-            if (EPI == 3) {
-                float ky = epi.Kyp[e];
-                for (int cb = 1; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
-                v = epi.mu[e] + ky;
-            } else {
-                v = epi.mu[e] + epi.Pcol[e];
-                epi.Pcol[e] = 0.f;
-            }
-            if (e >= 3 && e <= 6) s_q[e - 3] = v;
-            else epi.mu[e] = v;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): s_q written
-        __builtin_amdgcn_s_barrier();        // only the epilogue's 256 threads are left (WPS = 2: the others returned)
-        if (threadIdx.x < 4) {
-            const float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
-            epi.mu[3 + threadIdx.x] = s_q[threadIdx.x] / qn;
-        }
-        if (threadIdx.x == 0 && epi.frame_counter) {
-            const int fi = *epi.frame_counter + 1;
-            *epi.frame_counter = (fi >= epi.frames) ? 0 : fi;
-        }
-        for (int e = threadIdx.x; e < epi.n_zero; e += 256) epi.zero_words[e] = 0;  // the next update's sweep starts from zero flags
-    }
     float* cp = C + (size_t)jb * ldc + i0 + li;
     if (i0 + BMt <= M && j0 + 64 <= N) {  // interior tile: no per-element tests
 #pragma unroll
@@ -760,7 +772,7 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         const int wps = cfg >= 100 ? 1 : 2;  // 132 / 148 / 164: one wavefront per SIMD (micro-benchmark only)
         const int bm = cfg % 100;
         const int tx = (M + bm - 1) / bm;
-        dim3 grid(tiles(bm));
+        dim3 grid(tiles(bm) + ((e.mode == 2 || e.mode == 3) && e.n > 0 ? 1 : 0));  // (+1: gemm16_finish_mean)
 #define GEMM16_GO(BMv, W, EP)                                                                                           \
     hipLaunchKernelGGL((gemm16_kernel<BMv, W, EP>), grid, dim3(256 * W), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, \
                        ldc, flush, lowerB, e, tx, ty)
