@@ -531,6 +531,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, flo
         oy = next_px[2 * pt + 1];
     }
     bool ok = true;
+    unsigned itpack = 0u;
     for (int level = levels - 1; level >= 0; level--) {
         const LevelView I = P.lv[level];
         const LevelView J = Q.lv[level];
@@ -687,11 +688,13 @@ __global__ __launch_bounds__(64) void klt_track_kernel(PyrView P, PyrView Q, flo
         }
         KSTAMP(4 + 8 * level);
         if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[900 + 5 + 8 * level] = itc;
+        itpack |= (unsigned)itc << (8 * level);  // diagnostic: this landmark's Gauss-Newton steps, a byte per level
         if (ok && level == 0) {
             const int fx = (int)floorf(ox - half), fy = (int)floorf(oy - half);
             if (fx < -win || fx >= J.w || fy < -win || fy >= J.h) ok = false;
         }
     }
+    if (dbg && lane == 0 && pt < 896) dbg[pt] = (long long)itpack;  // (scripts/klt_iterations.py)
     if (lane == 0) {
         next_px[2 * pt] = ox;
         next_px[2 * pt + 1] = oy;
