@@ -18,6 +18,9 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 HOOKS_OBJ_DIR = os.path.join(LIB_DIR, "obj_hooks")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
          "-ffp-contract=off",  # the reference's x86-64 build never fuses multiply-add (parity)
+         # the library's only dynamic symbols are the entry points include/ekfvio.h marks EKFVIO_API (tests/test_abi_cpu.py checks
+         # the whole `nm -D --defined-only` set): no launcher, kernel stub or template instance can interpose in a node's process
+         "-fvisibility=hidden", "-fvisibility-inlines-hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 # per-file extras.  chol.hip: keep MFMA results in VGPRs: its dependent MFMA -> MFMA chains feed each
 # result straight back as an operand, and an AGPR destination costs a v_accvgpr_read per hop.
@@ -29,6 +32,7 @@ def sources():
 
 
 FLAGS_STAMP = os.path.join(LIB_DIR, ".build.flags")
+VERSION_SCRIPT = os.path.join(CSRC, "ekfvio.map")
 
 
 def _extra_flags():
@@ -39,89 +43,101 @@ def _flags_key():
     return " ".join(FLAGS + sorted("%s:%s" % kv for kv in ((k, " ".join(v)) for k, v in FILE_FLAGS.items())) + _extra_flags())
 
 
-def _stale():
-    """Only meaningful while holding the build lock (a concurrent builder replaces the library atomically, but the
-    object files and the flags stamp change underneath)."""
-    if not os.path.exists(LIB_PATH) or not os.path.exists(HOOKS_LIB_PATH) or not os.path.exists(FLAGS_STAMP) or not os.path.exists(ISA_STAMP):
-        return True  # (no ISA stamp: the hand-placed counted wait of chol.hip has not been checked against this library's compile)
-    if open(FLAGS_STAMP).read() != _flags_key():
-        return True  # e.g. a diagnostic build with pricing switches (wrong results) must not survive
-    t = min(os.path.getmtime(LIB_PATH), os.path.getmtime(HOOKS_LIB_PATH))
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), os.path.join(_HERE, "..", "include", "ekfvio_test_hooks.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+class _Variant:
+    """One build of the sources: the product library, or the same sources with -DEKFVIO_TEST_HOOKS."""
+
+    def __init__(self, hooks):
+        self.hooks = hooks
+        self.lib = HOOKS_LIB_PATH if hooks else LIB_PATH
+        self.obj_dir = HOOKS_OBJ_DIR if hooks else OBJ_DIR
+        self.defines = ["-DEKFVIO_TEST_HOOKS"] if hooks else []
+        self.flags_stamp = FLAGS_STAMP + (".hooks" if hooks else "")
+        self.isa_stamp = os.path.join(self.obj_dir, "chol.isa.checked")
+
+    def deps(self):
+        return (sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +
+                [VERSION_SCRIPT, os.path.join(_HERE, "..", "include", "ekfvio.h"), os.path.join(_HERE, "..", "include", "ekfvio_test_hooks.h"), __file__])
+
+    def stale(self):
+        """Only meaningful while holding the build lock (a concurrent builder replaces the library atomically, but the
+        object files and the flags stamp change underneath)."""
+        if not os.path.exists(self.lib) or not os.path.exists(self.flags_stamp) or not os.path.exists(self.isa_stamp):
+            return True  # (no ISA stamp: the hand-placed counted wait of chol.hip has not been checked against this library's compile)
+        if open(self.flags_stamp).read() != _flags_key():
+            return True  # e.g. a diagnostic build with pricing switches (wrong results) must not survive
+        t = os.path.getmtime(self.lib)
+        return any(os.path.getmtime(d) > t for d in self.deps())
 
 
-def build(force=False, verbose=False):
-    """Every caller takes the lock, decides staleness under it and links through a temporary name that is renamed
-    into place: the ranks of a multi-GPU launch all come through here at import, and none of them can map a
-    half-written library."""
+def build(force=False, verbose=False, hooks=False):
+    """Builds the product library; hooks=True: ALSO the hooks build (lazily: a deployment that ships only libekfvio_hip.so imports the
+    package without hipcc, and nothing but the tests and the profiling scripts asks for the other one -- ADVICE r05).  Every caller takes
+    the lock, decides staleness under it and links through a temporary name that is renamed into place: the ranks of a multi-GPU launch
+    all come through here at import, and none of them can map a half-written library."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(HOOKS_OBJ_DIR, exist_ok=True)
     import fcntl
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and not _stale():
-            return LIB_PATH
-        return _build_locked(force, verbose)
+        todo = [v for v in ([_Variant(False)] + ([_Variant(True)] if hooks else [])) if force or v.stale()]
+        if todo:
+            _build_locked(todo, force, verbose)
+        return HOOKS_LIB_PATH if hooks else LIB_PATH
 
 
-def _build_locked(force, verbose):
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(_HERE, "..", "include", "ekfvio.h"), os.path.join(_HERE, "..", "include", "ekfvio_test_hooks.h"), __file__]
-    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
-    if not os.path.exists(FLAGS_STAMP) or open(FLAGS_STAMP).read() != _flags_key():
-        force = True  # objects built with other flags
-    jobs, objs, hobjs = [], [], []
-    for src in sources():
-        name = os.path.basename(src)
-        for odir, define, olist in ((OBJ_DIR, [], objs), (HOOKS_OBJ_DIR, ["-DEKFVIO_TEST_HOOKS"], hobjs)):
-            obj = os.path.join(odir, name + ".o")
-            olist.append(obj)
-            if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+def _build_locked(variants, force, verbose):
+    jobs, isa_jobs = [], []
+    for v in variants:
+        newest_hdr = max(os.path.getmtime(h) for h in v.deps() if not h.endswith(".hip"))
+        vforce = force or not os.path.exists(v.flags_stamp) or open(v.flags_stamp).read() != _flags_key()  # objects built with other flags
+        v.objs = []
+        chol_rebuilt = False
+        for src in sources():
+            name = os.path.basename(src)
+            obj = os.path.join(v.obj_dir, name + ".o")
+            v.objs.append(obj)
+            if (not vforce and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
                     and os.path.getmtime(obj) >= newest_hdr):
                 continue
-            extra = _extra_flags()
-            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + extra + define + ["-c", "-o", obj, src]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + _extra_flags() + v.defines + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))
-    # chol.hip carries a hand-placed, COUNTED wait (chol_persist.inc: ready[k] goes up behind `s_waitcnt vmcnt(N)`): the ISA of
-    # the very compile that is being linked is checked, with the same flags, and the build fails on a mismatch
-    isa_job = None
-    if any(os.path.basename(c[-1]) == "chol.hip" and "-DEKFVIO_TEST_HOOKS" not in c for c, _ in jobs) or not os.path.exists(ISA_STAMP):
-        src = os.path.join(CSRC, "chol.hip")
-        isa = os.path.join(OBJ_DIR, "chol.device.s")
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get("chol.hip", []) + _extra_flags() + ["-S", "--cuda-device-only", "-o", isa, src]
-        if verbose:
-            print(" ".join(cmd))
-        isa_job = (cmd, subprocess.Popen(cmd), isa)
+            chol_rebuilt = chol_rebuilt or name == "chol.hip"
+        # chol.hip carries a hand-placed, COUNTED wait (chol_persist.inc: ready[k] goes up behind `s_waitcnt vmcnt(N)`): the ISA of
+        # the very compile that is being linked is checked, with the same flags and defines (the hooks build runs the abort and
+        # fault-injection tests and the stamp scripts on ITS chol_persist_kernel), and the build fails on a mismatch
+        if chol_rebuilt or not os.path.exists(v.isa_stamp):
+            src = os.path.join(CSRC, "chol.hip")
+            isa = os.path.join(v.obj_dir, "chol.device.s")
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get("chol.hip", []) + _extra_flags() + v.defines + ["-S", "--cuda-device-only", "-o", isa, src]
+            if verbose:
+                print(" ".join(cmd))
+            isa_jobs.append((v, cmd, subprocess.Popen(cmd), isa))
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    if isa_job:
-        cmd, pr, isa = isa_job
+    for v, cmd, pr, isa in isa_jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-        if os.path.exists(ISA_STAMP):
-            os.remove(ISA_STAMP)
+        if os.path.exists(v.isa_stamp):
+            os.remove(v.isa_stamp)
         problems = check_counted_waits(open(isa).read())
         if problems:
-            raise RuntimeError("chol.hip: hand-placed counted wait does not match the compiled ISA: " + "; ".join(problems))
-        with open(ISA_STAMP, "w") as fh:
+            raise RuntimeError("chol.hip%s: hand-placed counted wait does not match the compiled ISA: " % (" (hooks build)" if v.hooks else "") + "; ".join(problems))
+        with open(v.isa_stamp, "w") as fh:
             fh.write("ok\n")
-    for path, olist in ((LIB_PATH, objs), (HOOKS_LIB_PATH, hobjs)):
-        tmp = "%s.tmp.%d" % (path, os.getpid())
-        cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + olist
+    for v in variants:
+        tmp = "%s.tmp.%d" % (v.lib, os.getpid())
+        cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,--version-script=" + VERSION_SCRIPT, "-o", tmp] + v.objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        os.replace(tmp, path)  # atomic: a concurrent loader maps either the old or the new complete file
-    with open(FLAGS_STAMP + ".tmp", "w") as fh:
-        fh.write(_flags_key())
-    os.replace(FLAGS_STAMP + ".tmp", FLAGS_STAMP)
+        os.replace(tmp, v.lib)  # atomic: a concurrent loader maps either the old or the new complete file
+        with open(v.flags_stamp + ".tmp", "w") as fh:
+            fh.write(_flags_key())
+        os.replace(v.flags_stamp + ".tmp", v.flags_stamp)
     return LIB_PATH
-
-
-ISA_STAMP = os.path.join(OBJ_DIR, "chol.isa.checked")
 
 
 def check_counted_waits(isa_text):
@@ -187,5 +203,5 @@ def build_host(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True, hooks=True))
     print(build_host(force=True, verbose=True))

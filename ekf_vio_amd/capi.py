@@ -61,7 +61,7 @@ def load(build_if_missing=True, hooks=False):
         return _libs[hooks]
     path = _build.HOOKS_LIB_PATH if hooks else _build.LIB_PATH
     if build_if_missing:
-        _build.build()  # staleness is decided under the build lock; hipcc cross-compiles gfx950 with or without a GPU
+        _build.build(hooks=hooks)  # (the hooks build only when asked for) staleness is decided under the build lock; hipcc cross-compiles gfx950 with or without a GPU
     elif not os.path.exists(path):
         raise FileNotFoundError(path + " not built; run python -m ekf_vio_amd._build")
     lib = C.CDLL(path)

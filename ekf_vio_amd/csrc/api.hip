@@ -232,6 +232,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->early_status = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_UPLOAD_KERNEL");  // 0: the frame travels by the copy engine (hipMemcpyAsync) instead of the upload kernel
         if (e) f->upload_kernel = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_SWEEP_WAIT_MS");  // the persistent sweep's patience per wait where the update can be run again (default 3 ms)
+        if (e && atof(e) > 0) f->sweep_wait_ticks = (int)std::min(2.0e9, 1e5 * atof(e));
         e = getenv("EKFVIO_SWEEP_RETRY_S");  // the first pause before a handle whose persistent sweep gave up tries it again (default 2 s)
         if (e && atof(e) > 0) f->sweep_retry_first_s = atof(e);
         e = getenv("EKFVIO_SWEEP");  // tuning knob: 0 = one launch per block step
@@ -409,14 +411,23 @@ void sweep_abort_latch(ekfvio_filter* f) {
     f->sweep_retry_at = std::chrono::steady_clock::now() + std::chrono::milliseconds((long long)(1e3 * f->sweep_retry_pause_s));
     f->sweep_retry_armed = true;
 }
+// Called ONLY from the entry points that can run an aborted update again (ekfvio_update, ekfvio_step_image): a retry that fails costs
+// one recovery there, nothing else.
 void sweep_maybe_retry(ekfvio_filter* f) {
     if (!f->sweep_retry_armed || f->sweep_mode != 0 || std::chrono::steady_clock::now() < f->sweep_retry_at) return;
     f->sweep_retry_armed = false;
     f->sweep_mode = 2;
+    f->sweep_probation = 8;  // clean persistent sweeps until the pause starts from its first value again (sweep_clean_update)
     drop_graph(f);  // captured steps contain the per-step sweep
     // the flags AND the abort word (which no kernel ever zeroes) start from zero again
     (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * f->sweep_sync_words, f->stream);
     f->sweep_flags_clean = false;
+}
+// An update whose persistent sweep came through: after a few of them in a row behind a retry the pause of the NEXT abort starts from
+// its first value again (it only ever doubled, so a handle that met a few transient aborts early waited 64 s on the slow
+// sweep after any later one, even after hours of clean persistent sweeps).
+void sweep_clean_update(ekfvio_filter* f) {
+    if (f->sweep_probation > 0 && f->sweep_mode == 2 && --f->sweep_probation == 0) f->sweep_retry_pause_s = 0.0;
 }
 // Waits for the stream and reads the status word.  An aborted update is enqueued again by `rerun` (null: the caller cannot,
 // e.g. a graph replay of many steps: EKFVIO_EABORTED) with the per-step sweep and awaited: fresh launches, same inputs,
@@ -440,7 +451,7 @@ int finish_update_rerun(ekfvio_filter* f, void (*rerun)(ekfvio_filter*, void*), 
         if (rc != EKFVIO_OK) return rc;
         if (bad) HIPC(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
         if (bad & 2) return EKFVIO_EABORTED;  // (cannot happen: the per-step sweep has no waits)
-    }
+    } else if (rerun) sweep_clean_update(f);
     return (bad & 1) ? EKFVIO_ENUMERIC : EKFVIO_OK;
 }
 
@@ -746,9 +757,17 @@ int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt
     if (!f || f->seq_frames <= 0 || f->seq_N != f->N || count < 0 || first < 0 || !(dt >= 0.f)) return EKFVIO_EINVAL;
     f->out_fresh = false;
     HIPC(f, hipSetDevice(f->device));
-    sweep_maybe_retry(f);
+    // (no sweep_maybe_retry here -- ADVICE r05: a device-resident run cannot run an aborted update again, so a handle whose persistent
+    // sweep once gave up keeps the per-step sweep for its graph replays until ekfvio_update / ekfvio_step_image, which CAN recover,
+    // have tried the persistent launch again and it has come through; with a permanent obstacle (a compute-unit mask, a co-tenant
+    // process) a retry from here would skip a replay's remaining updates every 2 .. 64 s for the handle's whole life)
     const size_t N = f->N;
     int s = 0;
+    struct Unrec {  // the launches and captures of this call carry the long wait bound (common.h, sweep_wait_ticks): nothing can run their updates again
+        ekfvio_filter* f;
+        explicit Unrec(ekfvio_filter* f_) : f(f_) { f->sweep_unrecoverable = true; }
+        ~Unrec() { f->sweep_unrecoverable = false; }
+    } unrec(f);
     // hipGraph path: the same measurement-row count for every frame (one launch geometry),
     // profiling off.  The bookkeeping kernel reads the frame index from a device counter.
     // (count == 0 only prepares: the graphs are captured, nothing runs — callers that time a run call this first)

@@ -1076,11 +1076,11 @@ __global__ __launch_bounds__(256) void sign_irows_kernel(float* __restrict__ L, 
 }
 
 
-// Every wait inside the persistent sweep is bounded (chol_persist.inc, persist_poll): by wall-clock time, SWEEP_WAIT_TICKS of the
-// 100 MHz s_memrealtime counter = 3 ms (a filter step is 0.1 ms, the longest legitimate wait ~10 us), and by a number of looks that only
-// the fault-injection hook lowers into reach.
+// Every wait inside the persistent sweep is bounded (chol_persist.inc, persist_poll): by wall-clock time, PersistArgs::wait_ticks of the
+// 100 MHz s_memrealtime counter = 3 ms per handle by default (a filter step is 0.1 ms, the longest legitimate wait ~10 us), and by a
+// number of looks that only the fault-injection hook lowers into reach.
 #define SWEEP_SPIN_LIMIT (1 << 30)
-#define SWEEP_WAIT_TICKS 300000
+#define SWEEP_WAIT_TICKS_UNRECOVERABLE 10000000  // 100 ms: where nothing can run the update again (ekfvio_run_uploaded), PersistArgs::wait_ticks
 
 #include "chol_persist.inc"
 #include "chol_step_la.inc"
@@ -1204,7 +1204,8 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.K = f->Km, pa.ldk = f->ldp;
     f->gain_in_sweep = pa.gain != 0;
     pa.dbg = f->sweep_dbg;
-    pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+    pa.bound.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+    pa.bound.wait_ticks = f->sweep_unrecoverable ? std::max(f->sweep_wait_ticks, SWEEP_WAIT_TICKS_UNRECOVERABLE) : f->sweep_wait_ticks;
     pa.early_sources = f->persist_early;
     pa.stall_wg = f->sweep_stall_wg >= 0 ? f->sweep_stall_wg + pa.gather_wgs + 2 : -1;  // (the hook counts owners from workgroup 1)
     f->sweep_abort_word = pa.abort_flag;
@@ -1235,7 +1236,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         persist_flag_pointers(f, pa, mb, mb + rb);
         pa.fused = 0, pa.gather_wgs = 0, pa.gain = 0, pa.K = nullptr, pa.ldk = 0;
         pa.dbg = f->sweep_dbg;
-        pa.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+        pa.bound.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
+        pa.bound.wait_ticks = f->sweep_unrecoverable ? std::max(f->sweep_wait_ticks, SWEEP_WAIT_TICKS_UNRECOVERABLE) : f->sweep_wait_ticks;
         pa.early_sources = f->persist_early;
         pa.stall_wg = f->sweep_stall_wg;
         f->sweep_abort_word = pa.abort_flag;  // the kernels behind this sweep leave the state alone if it is raised (launch_update)

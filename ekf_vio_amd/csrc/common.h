@@ -122,6 +122,12 @@ struct ekfvio_filter {
     int upload_kernel = 1;             // EKFVIO_UPLOAD_KERNEL: the frame's trip to device memory is a kernel reading mapped host memory (klt.hip)
     bool sweep_retry_armed = false;    // an aborted persistent sweep latched sweep_mode to 0: tried again at sweep_retry_at (api.hip, sweep_maybe_retry)
     double sweep_retry_pause_s = 0.0, sweep_retry_first_s = 2.0;
+    int sweep_probation = 0;           // > 0: clean persistent sweeps still to come behind a retry before sweep_retry_pause_s starts over (api.hip)
+    int sweep_wait_ticks = 300000;     // the persistent sweep's patience per wait in 100 MHz ticks (3 ms; EKFVIO_SWEEP_WAIT_MS) where an aborted update
+                                       // is run again at once (ekfvio_update, ekfvio_step_image); a device-resident run (ekfvio_run_uploaded), which
+                                       // cannot, waits SWEEP_WAIT_TICKS_UNRECOVERABLE (100 ms): the counter also runs while a healthy sweep's
+                                       // wavefronts are descheduled (time slicing, a profiler's serialisation), ADVICE r05
+    bool sweep_unrecoverable = false;  // set by ekfvio_run_uploaded around its launches / captures
     std::chrono::steady_clock::time_point sweep_retry_at;
     bool graph_leaves_flags_clean = false;  // sweep_flags_clean as a replay of the captured step graphs leaves it (api.hip, capture_steps)
     bool sweep_flags_clean = false;   // the persistent sweep's flags are zero for the launch enqueued next (zeroed by the last GEMM of the
@@ -300,6 +306,7 @@ int next_status_seq(ekfvio_filter* f);
 // api.hip: what a host does when the status word says the persistent sweep gave up (bit 1): the handle goes to the per-step
 // sweep for good and its captured graphs are dropped
 void sweep_abort_latch(ekfvio_filter* f);
+void sweep_clean_update(ekfvio_filter* f);  // an update whose persistent sweep came through (api.hip)
 void sweep_maybe_retry(ekfvio_filter* f);  // at the entry points that enqueue updates: the persistent sweep again, some time after an abort
 int poll_status(ekfvio_filter* f, int seq, int* status, int* extra_out);
 // api.hip: addNewFeatures with the k new (u,v) already in f->zmeas on the device

@@ -1468,7 +1468,7 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
         if (rc != EKFVIO_OK) return rc;
         if (bad) HIPK(f, hipMemsetAsync(f->info, 0, sizeof(int), f->stream));
         if (bad & 2) return EKFVIO_EABORTED;
-    }
+    } else if (f->N > 0) sweep_clean_update(f);
     if (added > 0) {
         f->N += added;
         f->n += 3 * added;

@@ -27,6 +27,13 @@
 
 #include <stdint.h>
 
+/* The library is compiled with -fvisibility=hidden: the entry points marked EKFVIO_API are its ONLY dynamic symbols
+ * (tests/test_abi_cpu.py compares the whole `nm -D --defined-only` set with this header), so nothing of its internals can
+ * interpose on, or be interposed by, what else a ROS node links (OpenCV, tf, ...). */
+#ifndef EKFVIO_API
+#define EKFVIO_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -88,28 +95,28 @@ typedef struct ekfvio_config {
 } ekfvio_config;
 
 /* Fills `cfg` with the reference defaults (Params.h D_* values). */
-int ekfvio_default_config(ekfvio_config* cfg);
+EKFVIO_API int ekfvio_default_config(ekfvio_config* cfg);
 
 /* TightlyCoupledEKF::TightlyCoupledEKF() + initializeBaseState()
  * (TightlyCoupledEKF.cpp:10-56).  `device` is a HIP device ordinal.  `stream` is an
  * existing hipStream_t to enqueue on, or NULL to let the handle create its own.
  * On failure nothing is left allocated and *out is NULL. */
-int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out);
-int ekfvio_destroy(ekfvio_filter* f);
+EKFVIO_API int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_filter** out);
+EKFVIO_API int ekfvio_destroy(ekfvio_filter* f);
 /* initializeBaseState(): back to mu = [0,0,0,1,0...], Sigma diag [0x7,30x9,0.5x6], no landmarks. */
-int ekfvio_reset(ekfvio_filter* f);
-const char* ekfvio_last_error(const ekfvio_filter* f);
+EKFVIO_API int ekfvio_reset(ekfvio_filter* f);
+EKFVIO_API const char* ekfvio_last_error(const ekfvio_filter* f);
 
 /* addNewFeatures(std::vector<Eigen::Vector2f>) (TightlyCoupledEKF.cpp:58-94). */
-int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count);
+EKFVIO_API int ekfvio_add_features(ekfvio_filter* f, const float* uv, int32_t count);
 
 /* process(float dt) (TightlyCoupledEKF.cpp:96-121): FD linearisation, mean propagation,
  * Sigma <- F Sigma F^T + Q(dt), flush below 1e-13. */
-int ekfvio_process(ekfvio_filter* f, float dt);
+EKFVIO_API int ekfvio_process(ekfvio_filter* f, float dt);
 
 /* numericallyLinearizeProcess (TightlyCoupledEKF.cpp:176-325): writes the dense n x n
  * Jacobian (column-major, ld = n) to host memory.  Does not change the state. */
-int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense);
+EKFVIO_API int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense);
 
 /* updateWithFeaturePositions(z, R, pass) (TightlyCoupledEKF.cpp:475-628).  `count` must
  * equal the number of landmarks (reference ROS_ASSERT at :478).  Entries of z/R for
@@ -117,68 +124,68 @@ int ekfvio_linearize(ekfvio_filter* f, float dt, float* F_dense);
  * recovered inside the call, see EKFVIO_EABORTED).  The call returns as soon as the update's status is known -- when the
  * Cholesky sweep has ended; the covariance update behind it may still be running: every later call on this handle is ordered
  * behind it or waits for it (ekfvio_synchronize waits explicitly). */
-int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count);
+EKFVIO_API int ekfvio_update(ekfvio_filter* f, const float* z, const float* R, const uint8_t* pass, int32_t count);
 
 /* formFeatureMeasurementMap (TightlyCoupledEKF.cpp:634-661): state index of the single 1.0
  * in each row of H.  Writes 2*(#measured) ints, returns that count through *rows. */
-int ekfvio_measurement_map(const ekfvio_filter* f, const uint8_t* measured, int32_t count, int32_t* idx, int32_t* rows);
+EKFVIO_API int ekfvio_measurement_map(const ekfvio_filter* f, const uint8_t* measured, int32_t count, int32_t* idx, int32_t* rows);
 
 /* previousFeaturePositionVector() (TightlyCoupledEKF.cpp:462-470) and the landmark records
  * (Feature.h:41-46).  Any pointer may be NULL. */
-int ekfvio_num_features(const ekfvio_filter* f);
-int ekfvio_dim(const ekfvio_filter* f); /* 22 + 3N */
-int ekfvio_get_base_mu(ekfvio_filter* f, float base_mu[EKFVIO_BASE_STATE_SIZE]);
-int ekfvio_get_features(ekfvio_filter* f, float* mu3N, float* last_klt2N, uint8_t* delete_flagN);
-int ekfvio_get_sigma(ekfvio_filter* f, float* sigma, int32_t ld);
+EKFVIO_API int ekfvio_num_features(const ekfvio_filter* f);
+EKFVIO_API int ekfvio_dim(const ekfvio_filter* f); /* 22 + 3N */
+EKFVIO_API int ekfvio_get_base_mu(ekfvio_filter* f, float base_mu[EKFVIO_BASE_STATE_SIZE]);
+EKFVIO_API int ekfvio_get_features(ekfvio_filter* f, float* mu3N, float* last_klt2N, uint8_t* delete_flagN);
+EKFVIO_API int ekfvio_get_sigma(ekfvio_filter* f, float* sigma, int32_t ld);
 /* getFeatureHomogenousCovariance / getFeatureDepthVariance (TightlyCoupledEKF.cpp:663-681). */
-int ekfvio_get_feature_cov(ekfvio_filter* f, int32_t index, float cov2x2[4]);
-int ekfvio_get_depth_variance(ekfvio_filter* f, int32_t index, float* var);
+EKFVIO_API int ekfvio_get_feature_cov(ekfvio_filter* f, int32_t index, float cov2x2[4]);
+EKFVIO_API int ekfvio_get_depth_variance(ekfvio_filter* f, int32_t index, float* var);
 /* setFeatureHomogenousCovariance(index, cov) (TightlyCoupledEKF.cpp:668-676): overwrites the 2x2 (u,v) block of Sigma
  * (column-major, like Eigen::Matrix2f). */
-int ekfvio_set_feature_cov(ekfvio_filter* f, int32_t index, const float cov2x2[4]);
+EKFVIO_API int ekfvio_set_feature_cov(ekfvio_filter* f, int32_t index, const float cov2x2[4]);
 /* getMetric2PixelMap(K) / getPixel2MetricMap(K) (TightlyCoupledEKF.cpp:683-697): J = diag(K(0,0), K(1,1)) and
  * diag(1/K(0,0), 1/K(1,1)), column-major 2x2; K row-major 3x3 as in CameraInfo.K.  Pure functions of K. */
-int ekfvio_metric2pixel_map(const float K[9], float J2x2[4]);
-int ekfvio_pixel2metric_map(const float K[9], float J2x2[4]);
+EKFVIO_API int ekfvio_metric2pixel_map(const float K[9], float J2x2[4]);
+EKFVIO_API int ekfvio_pixel2metric_map(const float K[9], float J2x2[4]);
 /* What EKFVIO::publishOdometry puts into nav_msgs/Odometry (EKFVIO.cpp:444-477): position base_mu[0..2], orientation
  * (w,x,y,z) base_mu[3..6], linear twist base_mu[7..9], angular twist base_mu[10..12].  Any pointer may be NULL. */
-int ekfvio_get_odometry(ekfvio_filter* f, float position[3], float orientation_wxyz[4], float linear[3], float angular[3]);
+EKFVIO_API int ekfvio_get_odometry(ekfvio_filter* f, float position[3], float orientation_wxyz[4], float linear[3], float angular[3]);
 /* What EKFVIO::publishPoints puts into sensor_msgs/PointCloud (EKFVIO.cpp:479-518), formed on the device: camera-frame
  * xyz = (u/rho, v/rho, 1/rho) per landmark and the "intensity" channel = byte of the current (resized) frame at the
  * landmark's pixel (Feature::getPixel, rounded like cv::Point(cv::Point2f)); 0 for a pixel outside the image (the
  * reference reads unchecked there) or before the first frame.  Either pointer may be NULL. */
-int ekfvio_get_points(ekfvio_filter* f, float* xyz3N, float* intensityN);
+EKFVIO_API int ekfvio_get_points(ekfvio_filter* f, float* xyz3N, float* intensityN);
 /* checkSigma (TightlyCoupledEKF.cpp:699-714) as numbers: min diagonal, max |S_ij - S_ji|. */
-int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym);
+EKFVIO_API int ekfvio_check_sigma(ekfvio_filter* f, float* min_diag, float* max_asym);
 
 /* Checkpoint / teacher-forcing hook (the reference has none; its members are public). */
-int ekfvio_set_state(ekfvio_filter* f, int32_t n_features, const float* base_mu, const float* mu3N,
+EKFVIO_API int ekfvio_set_state(ekfvio_filter* f, int32_t n_features, const float* base_mu, const float* mu3N,
                      const float* last_klt2N, const uint8_t* delete_flagN, const float* sigma, int32_t ld);
 
 /* ---- KLT (KLTTracker::findNewFeaturePositions, KLTTracker.cpp:29-95) ----------------- */
 /* Uploads a frame (Frame.h:25-41: image + intrinsics K row-major 3x3 as in CameraInfo.K),
  * builds its pyramid and Scharr derivatives on the device and makes it the current frame;
  * the former current frame becomes the previous one (frame_buffer depth 2, Params.h:58). */
-int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+EKFVIO_API int ekfvio_klt_push_frame(ekfvio_filter* f, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                           const float K[9]);
 /* Tracks every landmark from the previous into the current frame: reference points are the
  * landmarks' last KLT results, initial guesses the EKF-predicted positions.  Outputs metric
  * z (2N), metric R (4N, 1e-5 px^2 scaled by 1/fx^2, 1/fy^2), pass (N).  Host pointers; any may be NULL. */
-int ekfvio_klt_track(ekfvio_filter* f, float* z2N, float* R4N, uint8_t* passN);
+EKFVIO_API int ekfvio_klt_track(ekfvio_filter* f, float* z2N, float* R4N, uint8_t* passN);
 /* Pixel-space tracking of arbitrary points (calcOpticalFlowPyrLK semantics with
  * OPTFLOW_USE_INITIAL_FLOW) between the two resident frames; for tests. */
-int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float* init_px, int32_t count,
+EKFVIO_API int ekfvio_klt_track_points(ekfvio_filter* f, const float* prev_px, const float* init_px, int32_t count,
                             float* out_px, uint8_t* status);
 
 /* KLTTracker::estimateUncertaintySampleBased (KLTTracker.cpp:111-175) between the two resident frames: for every
  * point a pixel-space 2x2 covariance (row-major, px^2) from 25 samples (offsets -10..10 step 5 around cur_px) of 5x5
  * sub-pixel patches (cv::getRectSubPix semantics) weighted by exp(-0.01 * mean squared difference to the 5x5
  * reference patch at ref_px in the previous frame).  Host pointers. */
-int ekfvio_klt_uncertainty_points(ekfvio_filter* f, const float* ref_px, const float* cur_px, int32_t count, float* cov4);
+EKFVIO_API int ekfvio_klt_uncertainty_points(ekfvio_filter* f, const float* ref_px, const float* cur_px, int32_t count, float* cov4);
 
 /* Test hook: interior of pyramid level `level` of the current frame (8-bit image, w*h, and
  * interleaved int16 Scharr dx,dy, w*h*2).  Either output may be NULL. */
-int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h, uint8_t* img, int16_t* deriv);
+EKFVIO_API int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h, uint8_t* img, int16_t* deriv);
 
 /* EKFVIO::addFrame + updateStateWithNewImage (EKFVIO.cpp:139-219) without the ROS
  * publishing: first frame only stores the image and stamp; later frames run
@@ -190,7 +197,7 @@ int ekfvio_klt_get_level(ekfvio_filter* f, int32_t level, int32_t* w, int32_t* h
  * ekfvio_synchronize) polls a word the device writes into pinned host memory for up to 300 us of the calling
  * thread's time, then blocks in hipStreamSynchronize.
  * Returns EKFVIO_OK or EKFVIO_ENUMERIC. */
-int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height,
+EKFVIO_API int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int32_t width, int32_t height,
                       int32_t stride, const float K[9]);
 
 /* EKFVIO::replenishFeatures (EKFVIO.cpp:224-311) on the current frame: cv::FAST(threshold, nonmax) on the
@@ -198,53 +205,53 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
  * in detector order with the kill-box test, addNewFeatures(pixel2Metric(.)) until max_features landmarks
  * exist.  `added` (may be NULL) receives the number of new landmarks, new_px_xy (may be NULL, room for
  * 2*max_features ints) their pixels. */
-int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy);
+EKFVIO_API int ekfvio_replenish(ekfvio_filter* f, int32_t* added, int32_t* new_px_xy);
 /* Test hook: cv::FAST(level 0 of the current frame, blurred first if cfg.fast_blur_sigma != 0, threshold, nonmax),
  * TYPE_9_16, keypoints in raster order. */
-int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score,
+EKFVIO_API int ekfvio_fast_detect(ekfvio_filter* f, int32_t threshold, int32_t nonmax, int32_t cap, int32_t* xy, int32_t* score,
                        int32_t* count);
 /* EKFVIO::imu_callback (EKFVIO.cpp:113-115), a logging stub in the reference: with cfg.use_imu = 0 (default) this does
  * nothing.  With cfg.use_imu = 1 the record first propagates the filter to its stamp -- process(dt = stamp - t),
  * the reference's motion model; the first record or frame only sets t -- and then updates with z = [gyro; accel],
  * h = [omega + b_gyr; a + b_acc - R(q)^T gravity], Joseph form (specification: oracle/ekf_oracle.hpp imu_update).
  * EKFVIO_EINVAL for a stamp before the filter's time.  Asynchronous. */
-int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float accel[3]);
+EKFVIO_API int ekfvio_imu(ekfvio_filter* f, double stamp, const float gyro[3], const float accel[3]);
 /* The update alone (no propagation), whatever cfg.use_imu says: for tests and callers that propagate themselves. */
-int ekfvio_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[3]);
+EKFVIO_API int ekfvio_imu_update(ekfvio_filter* f, const float gyro[3], const float accel[3]);
 
 /* ---- device-resident measurement sequences (benchmark / replay) ---------------------- */
 /* Copies `frames` consecutive (z, R, pass) triples for the current landmark count to HBM. */
-int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z, const float* R, const uint8_t* pass);
+EKFVIO_API int ekfvio_upload_measurements(ekfvio_filter* f, int32_t frames, const float* z, const float* R, const uint8_t* pass);
 /* Runs process(dt) + update(frame i) for i = first .. first+count-1 (indices wrap modulo the
  * uploaded frame count) with no host<->device traffic.  Asynchronous; pair with
  * ekfvio_synchronize.  count = 0 runs nothing but prepares the launch graphs the runs replay (their
  * capture costs milliseconds: a caller that times a run prepares first). */
-int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt);
+EKFVIO_API int ekfvio_run_uploaded(ekfvio_filter* f, int32_t first, int32_t count, float dt);
 /* Waits for the handle's stream.  Returns EKFVIO_ENUMERIC (once) if a run since the last status read met a
  * non-positive pivot (reference: ROS_ERROR_COND at TightlyCoupledEKF.cpp:579, continues); EKFVIO_EABORTED if a persistent
  * sweep of the run gave up (the updates behind it were skipped; see the enum); else EKFVIO_OK. */
-int ekfvio_synchronize(ekfvio_filter* f);
+EKFVIO_API int ekfvio_synchronize(ekfvio_filter* f);
 
 /* ---- instrumentation ----------------------------------------------------------------- */
 /* Per-kernel-class device time accumulated with HIP events on the handle's stream while
  * profiling is on.  Classes: see ekfvio_profile_name.  Times in milliseconds. */
-int ekfvio_profile_enable(ekfvio_filter* f, int32_t on);
-int ekfvio_profile_reset(ekfvio_filter* f);
-int ekfvio_profile_count(void);
-const char* ekfvio_profile_name(int32_t cls);
-int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t* launches, double* flops);
+EKFVIO_API int ekfvio_profile_enable(ekfvio_filter* f, int32_t on);
+EKFVIO_API int ekfvio_profile_reset(ekfvio_filter* f);
+EKFVIO_API int ekfvio_profile_count(void);
+EKFVIO_API const char* ekfvio_profile_name(int32_t cls);
+EKFVIO_API int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_ms, int64_t* launches, double* flops);
 /* Mean launch duration (us) of the P-update GEMM(s) at the shape of the most recent update -- Sigma' = T + G K^T, and,
  * where the sweep does not produce T itself (EKFVIO_SCHUR=0, m >= 1024), T = Sigma - K W as well -- `reps` repetitions
  * replayed back to back from one hipGraph between two HIP events on the handle's stream; results go to scratch, the
  * state is untouched.  flops_per_launch = 2 n n m_pad (may be NULL). */
-int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_launch_us, double* flops_per_launch);
+EKFVIO_API int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_launch_us, double* flops_per_launch);
 
 /* Diagnostic counters of a handle (no device work): counters[0] Cholesky sweeps that went out as the single persistent launch
  * (chol_persist_kernel; the others took one launch per block step), [1] sweeps with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1),
  * [2] updates run again behind an aborted persistent sweep, [3] the handle's sweep mode now (2: persistent where it applies, 0: one launch
  * per block step), [4] frames of ekfvio_step_image whose outputs and status were published between the update's two Joseph GEMMs,
  * [5..7] reserved (0). */
-int ekfvio_get_counters(ekfvio_filter* f, int64_t counters[8]);
+EKFVIO_API int ekfvio_get_counters(ekfvio_filter* f, int64_t counters[8]);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,9 @@ def test_aborted_update_is_rerun_with_the_per_step_sweep_bit_for_bit(monkeypatch
     g.close()
 
 
-def test_aborted_device_resident_run_reports_eaborted_and_leaves_a_valid_state():
+def test_aborted_device_resident_run_reports_eaborted_and_leaves_a_valid_state(monkeypatch):
+    import time
+    monkeypatch.setenv("EKFVIO_SWEEP_RETRY_S", "0.2")
     N = 256
     sc, st, frames = _warm_state(N)
     z = np.stack([f[0] for f in frames]).astype(np.float32)
@@ -104,12 +106,25 @@ def test_aborted_device_resident_run_reports_eaborted_and_leaves_a_valid_state()
     h.close()
     for k in ("base_mu", "feat_mu", "Sigma"):
         assert np.array_equal(got[k], only_predicted[k]), k
-    assert g.sweep_counts()["mode"] == 0
-    # the next run goes through (per-step sweep) and is reported clean
+    c0 = g.sweep_counts()
+    assert c0["mode"] == 0
+    # the next run goes through (per-step sweep) and is reported clean -- also once the retry pause has passed: a device-resident run
+    # cannot run an aborted update again, so it never re-arms the persistent launch by itself; an entry point that can
+    # recover (ekfvio_update) does, and the runs behind its clean retry are persistent again
     g.sweep_fault(0, -1)
+    time.sleep(0.3)
     g.run_uploaded(0, 2, sc.dt)
     assert g.synchronize() in (capi.OK, capi.ENUMERIC)
     assert np.isfinite(g.get_state()["Sigma"]).all()
+    c1 = g.sweep_counts()
+    assert c1["mode"] == 0 and c1["persistent"] == c0["persistent"], (c0, c1)
+    g.process(sc.dt)
+    assert g.updateWithFeaturePositions(*frames[0]) in (capi.OK, capi.ENUMERIC)
+    c2 = g.sweep_counts()
+    assert c2["mode"] == 2 and c2["persistent"] == c1["persistent"] + 1 and c2["recoveries"] == c1["recoveries"], (c1, c2)
+    g.run_uploaded(0, 2, sc.dt)
+    assert g.synchronize() in (capi.OK, capi.ENUMERIC)
+    assert g.sweep_counts()["persistent"] > c2["persistent"]
     g.close()
 
 
@@ -193,18 +208,22 @@ def test_a_latched_handle_tries_the_persistent_sweep_again_later(monkeypatch):
     g = TightlyCoupledEKF(max_features=N, hooks=True)
     g.set_state(st)
     g.sweep_fault(spin_limit=200, stall_workgroup=7)
+    retried = 0
     for i, (z, R, p) in enumerate(frames[:3]):
         if i == 1:
             c = g.sweep_counts()
-            assert c["mode"] == 0 and c["recoveries"] == 1, c   # latched by the first update's abort
+            assert c["mode"] == 0 and c["recoveries"] == 1 and c["persistent"] == 1, c   # latched by the first update's abort
             g.sweep_fault(spin_limit=0, stall_workgroup=-1)      # the obstacle goes away ...
         if i == 2:
             time.sleep(0.3)                                      # ... and the pause passes
         g.process(sc.dt)
         assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
+        if i >= 1 and g.sweep_counts()["mode"] == 2:
+            retried += 1  # (counted, not assumed from the sleep: on a slow box the pause may already have passed at i == 1 -- ADVICE r05)
         got = g.get_state()
         for k in KEYS:
             assert np.array_equal(got[k], want[i][k]), (i, k)
     c = g.sweep_counts()
-    assert c["mode"] == 2 and c["persistent"] == 2 and c["recoveries"] == 1, c  # tried twice: aborted once, clean the second time
+    # aborted once, clean from the retry on: every update behind the retry was a persistent sweep, none needed a recovery
+    assert retried >= 1 and c["mode"] == 2 and c["persistent"] == 1 + retried and c["recoveries"] == 1, (c, retried)
     g.close()
