@@ -240,6 +240,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->sweep_mode = atoi(e) ? 2 : 0;
         e = getenv("EKFVIO_FUSE_GATHER");  // tuning knob: 0 = gather and first diagonal tile in separate launches
         if (e) f->fuse_gather = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_T2");  // A/B knob: 0 = gain in the sweep, two Joseph GEMMs behind it (rounds 4-5)
+        if (e) f->t2_flow = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_SCHUR");  // tuning knob: 1 = Sigma (I - K H)^T and K as Schur tiles inside the sweep instead of two GEMMs behind it
         if (e) f->schur = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FRAME_OUTPUTS");  // tuning knob: 0 = the frame's last kernel publishes the status word only
@@ -902,7 +904,8 @@ int ekfvio_get_counters(ekfvio_filter* f, int64_t counters[8]) {
     counters[2] = f->sweep_recoveries;
     counters[3] = f->sweep_mode;
     counters[4] = f->early_output_frames;
-    counters[5] = counters[6] = counters[7] = 0;
+    counters[5] = f->t2_updates;
+    counters[6] = counters[7] = 0;
     return EKFVIO_OK;
 }
 

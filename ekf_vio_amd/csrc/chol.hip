@@ -1136,9 +1136,9 @@ void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_o
 
 // helpers of the persistent sweep (chol_persist.inc): per block column j the rows of A from the diagonal down (without
 // (1,1)), the X row blocks and the identity row blocks 0 .. j
-static int persist_helpers(int mb, int nX) {
+static int persist_helpers(int mb, int nX, bool compact = false) {  // (compact: without the identity rows' diagonal tiles, chol_persist.inc)
     int h = 0;
-    for (int j = 1; j < mb; j++) h += (mb - j - (j == 1 ? 1 : 0)) + nX + (j + 1);
+    for (int j = 1; j < mb; j++) h += (mb - j - (j == 1 ? 1 : 0)) + nX + (j + 1 - (compact ? 1 : 0));
     return h;
 }
 // The shapes the persistent launch takes: 3 .. EKF_SWEEP_SPLIT_MB - 1 block columns.  Up to round 3: chain + owners co-resident
@@ -1167,6 +1167,21 @@ static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB;
     return persist_shape(f, m_pad, n_pad) && 1 + mb * (f->ldp / 64) + 2 + persist_helpers(mb, n_pad / PB) <= f->num_cus + 8;
 }
+// ... and of those, the shapes whose T2 = Sigma (I - K H)^T is formed by freed owners inside the launch (round 6, chol_persist.inc, t2_tile): there
+// must be an owner per tile pair once enough of the first owners have LEFT for every workgroup of the launch to find a compute unit (the two
+// step-0 gatherers and the gain workgroups beyond the state's row blocks leave at once).  Returns the number of owners that leave (PersistArgs::t2_skip),
+// -1 where the flow does not apply.  The flow is a property of the SHAPE, not of the sweep that runs: behind a per-step sweep of such a shape
+// t2_tiles_kernel forms the same T2, so a sequence's bits do not depend on what else the device runs.
+static int t2_skip_owners(const ekfvio_filter* f, int m_pad, int n_pad) {
+    if (!f->t2_flow || !f->persist_gain || f->schur || !gain_in_sweep_shape(f, m_pad, n_pad)) return -1;
+    const int mb = m_pad / PB, nX = n_pad / PB;
+    const int H = persist_helpers(mb, nX, true), gw = mb * (f->ldp / 64);
+    if (1 + gw + H > f->num_cus) return -1;  // the compact launch (chol_persist.inc): every workgroup has its compute unit from the start
+    static const int skip_env = getenv("EKFVIO_T2_SKIP") ? atoi(getenv("EKFVIO_T2_SKIP")) : -1;  // (experiment knob)
+    const int skip = skip_env >= 0 ? skip_env : 0;
+    return (nX * (nX + 1) / 2 <= H - skip) ? skip : -1;
+}
+bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad) { return t2_skip_owners(f, m_pad, n_pad) >= 0; }
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {
     // (only for a device's sole handle: two persistent launches in flight together could starve each other of compute units)
     return f->sweep_mode == 2 && !sweep_supports_schur(f, m_pad) && live_handles_on(f->device) <= 1 && persist_shape(f, m_pad, n_pad);
@@ -1203,15 +1218,20 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.gain = (f->persist_gain && gain_in_sweep_shape(f, m_pad, n_pad)) ? 1 : 0;
     pa.K = f->Km, pa.ldk = f->ldp;
     f->gain_in_sweep = pa.gain != 0;
+    pa.t2_skip = t2_skip_owners(f, m_pad, n_pad);
+    pa.t2 = (pa.gain && pa.t2_skip >= 0) ? 1 : 0;
+    pa.compact = pa.t2;
+    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = f->P2, pa.ldt = f->ldp, pa.nstate = f->n;
+    f->t2_in_sweep = pa.t2 != 0;
     pa.dbg = f->sweep_dbg;
     pa.bound.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
     pa.bound.wait_ticks = f->sweep_unrecoverable ? std::max(f->sweep_wait_ticks, SWEEP_WAIT_TICKS_UNRECOVERABLE) : f->sweep_wait_ticks;
     pa.early_sources = f->persist_early;
-    pa.stall_wg = f->sweep_stall_wg >= 0 ? f->sweep_stall_wg + pa.gather_wgs + 2 : -1;  // (the hook counts owners from workgroup 1)
+    pa.stall_wg = f->sweep_stall_wg >= 0 ? f->sweep_stall_wg + pa.gather_wgs + (pa.compact ? 0 : 2) : -1;  // (the hook counts owners from workgroup 1)
     f->sweep_abort_word = pa.abort_flag;
     if (!f->sweep_flags_clean) (void)hipMemsetAsync(f->sweep_sync, 0, sizeof(int) * persist_flag_words(m_pad, n_pad), f->stream);
     f->sweep_flags_clean = false;
-    hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + pa.gather_wgs + 2 + persist_helpers(mb, n_pad / PB)), dim3(256), EKF_PERSIST_FUSED_DYN_LDS,
+    hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + pa.gather_wgs + (pa.compact ? 0 : 2) + persist_helpers(mb, n_pad / PB, pa.compact != 0)), dim3(256), EKF_PERSIST_FUSED_DYN_LDS,
                        f->stream, pa, ga);
     f->persistent_sweeps++;
 }
@@ -1225,6 +1245,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
     const int idb0 = mb + n_pad / PB;
     f->sweep_abort_word = nullptr;
     f->gain_in_sweep = false;
+    f->t2_in_sweep = false;
     if (!first_tile_done)
         hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, f->info, f->Lsign);
     if (!schur && sweep_is_persistent(f, m_pad, n_pad)) {
@@ -1234,7 +1255,7 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         pa.mb = mb, pa.idb0 = idb0, pa.nrows = mb + rb;
         pa.info = f->info, pa.Lsign = f->Lsign;
         persist_flag_pointers(f, pa, mb, mb + rb);
-        pa.fused = 0, pa.gather_wgs = 0, pa.gain = 0, pa.K = nullptr, pa.ldk = 0;
+        pa.fused = 0, pa.gather_wgs = 0, pa.gain = 0, pa.K = nullptr, pa.ldk = 0, pa.t2 = 0, pa.compact = 0;
         pa.dbg = f->sweep_dbg;
         pa.bound.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
         pa.bound.wait_ticks = f->sweep_unrecoverable ? std::max(f->sweep_wait_ticks, SWEEP_WAIT_TICKS_UNRECOVERABLE) : f->sweep_wait_ticks;
@@ -1366,9 +1387,34 @@ __global__ __launch_bounds__(256) void joseph_g_kernel(float* __restrict__ K, in
     if (ph == 0) Kyp[(size_t)blockIdx.y * ldg + i] = ((s_part[0][rl] + s_part[1][rl]) + s_part[2][rl]) + s_part[3][rl];
 }
 
-void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
+// T2 behind a sweep that did not form it itself (t2_tiles_kernel): Sigma = f->P in, T2 -> f->P2
+void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad) {
+    ProfScope ps(f, PC_SOLVE, (double)n_pad * n_pad * m_pad);
+    PersistArgs pa = PersistArgs();
+    pa.L = f->Laug, pa.ldl = f->ld_aug;
+    pa.mb = m_pad / PB, pa.idb0 = m_pad / PB + n_pad / PB;
+    pa.Lsign = f->Lsign;
+    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = f->P2, pa.ldt = f->ldp, pa.nstate = f->n;
+    const int nX = n_pad / PB;
+    hipLaunchKernelGGL(t2_tiles_kernel, dim3(nX * (nX + 1) / 2), dim3(256), 0, f->stream, pa);
+}
+
+// The gain, G' and K y's partial sums behind a sweep that did not form them itself (gain2_tiles_kernel; T2 flow)
+void launch_gain2_tiles(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
+    ProfScope ps(f, PC_SOLVE, 2.0 * n_pad * (double)m_pad * m_pad);
+    PersistArgs pa = PersistArgs();
+    pa.L = f->Laug, pa.ldl = f->ld_aug;
+    pa.mb = m_pad / PB, pa.idb0 = m_pad / PB + n_pad / PB;
+    pa.K = f->Km, pa.ldk = f->ldp;
+    pa.Lsign = f->Lsign;
+    GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
+    if (m_on_device) ga.m_dev = f->info + 2;
+    hipLaunchKernelGGL(gain2_tiles_kernel, dim3((n_pad / PB) * pa.mb), dim3(256), 0, f->stream, pa, ga);
+}
+
+void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, const float* T) {
     ProfScope ps(f, PC_SOLVE, 3.0 * n_pad * (double)m_pad);
-    hipLaunchKernelGGL(joseph_g_kernel, dim3(n_pad / 64, m_pad / 64), dim3(256), 0, f->stream, f->Km, f->ldp, f->P, f->ldp, f->idx,
+    hipLaunchKernelGGL(joseph_g_kernel, dim3(n_pad / 64, m_pad / 64), dim3(256), 0, f->stream, f->Km, f->ldp, T ? T : f->P, f->ldp, f->idx,
                        f->Rm, f->yres, f->mu, m, m_on_device ? f->info + 2 : nullptr, f->Gm, f->ldp, f->Wt);
 }
 

@@ -112,6 +112,7 @@ struct ekfvio_filter {
     long long sweep_recoveries = 0;   // updates run again with the per-step sweep behind an aborted persistent launch
     int early_outputs = 1;            // EKFVIO_EARLY_OUTPUTS: a frame's outputs and status go out between the update's two Joseph GEMMs (klt.hip)
     void (*between_joseph)(ekfvio_filter*) = nullptr;  // ekfvio_step_image: called by launch_update between the update's two Joseph GEMMs (the frame's outputs)
+    int hook_kyp_blocks = 0;          // > 0 while between_joseph is called from the T2 flow: K y is Wt's first rows (one per block column), not column n of P
     int between_joseph_seq = 0;       // ... and the status sequence number its launch publishes (0: not called)
     long long early_output_frames = 0;  // frames whose outputs went out that way (test hook)
     int publish_after_sweep_seq = 0;  // ekfvio_update: launch_update publishes the status word with this sequence number right behind the sweep (0: not asked)
@@ -140,6 +141,10 @@ struct ekfvio_filter {
     int persist_early = 1;            // 1 (EKFVIO_PERSIST_EARLY=0 turns it off): owners fetch their panel sources in front of the wait for ready[k] (chol_persist.inc)
     int fuse_gather = 1;       // 1: the gather and the first diagonal tile's factorisation share a launch (EKFVIO_FUSE_GATHER)
     bool gather_attr_set = false;
+    int t2_flow = 1;           // 1 (EKFVIO_T2=0 turns it off): where the fused persistent launch forms the gain, freed owners also form T2 = Sigma (I - K H)^T
+                               // (chol_persist.inc, t2_tile): Sigma' = T2 + K G'^T is the ONE P-update GEMM behind the launch (round 6)
+    long long t2_updates = 0;  // updates enqueued (or captured) with the T2 flow: ONE P-update GEMM behind the sweep (ekfvio_get_counters [5])
+    bool t2_in_sweep = false;  // the sweep enqueued last formed T2 itself (launch_update then skips t2_tiles_kernel)
     int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.
                                // Measured equal in step time at N = 256, so the simpler flow is the default.
     int fuse_linearize = 1;    // 1: structured process(dt) is one launch, the Jacobian blocks are formed inside it (EKFVIO_FUSE_LINEARIZE)
@@ -328,7 +333,10 @@ int persist_zero_words(int m_pad, int n_pad);
 void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 int live_handles_on(int device);  // api.hip: handles alive on that device in this process
 // K pruned, G = K R - T[:, idx], K y partial sums (one row of f->Wt per 64 measurement columns)
-void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
+void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, const float* T = nullptr);  // T: the covariance G' is taken from (null: f->P)
+bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad);  // chol.hip: T2 = Sigma (I - K H)^T comes out of the sweep (or t2_tiles_kernel), ONE Joseph GEMM behind it
+void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad);
+void launch_gain2_tiles(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false, bool with_wt = true);
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);
 // K = X A^-1 (n rows, ldk) from the sweep output: K = Y L^-1 (+ optional residual refinement).

@@ -1034,7 +1034,29 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         e1.G = f->Gm;
         e1.ldg = ld;
         e1.abort = e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: both GEMMs write nothing
-        {
+        if (t2_flow_shape(f, m_pad, n_pad)) {
+            // Round 6: T2 = Sigma - Y S Y^T = Sigma (I - K H)^T came out of the persistent launch itself (freed owners, chol_persist.inc t2_tile; behind
+            // any other sweep of such a shape t2_tiles_kernel forms the same T2 from the stored panel blocks), in f->P2; the gain tiles of the same
+            // launch (gain_tile2; gain2_tiles_kernel otherwise) left K, G' = K R^T - (H T2)^T and the partial sums of K y.  The left Joseph factor is the ONE P-update GEMM:
+            // Sigma' = (I - K H) T2 + K R K^T = T2 + K G'^T (:594-596), pruned (:625), into f->P; its extra workgroup finishes the mean (:600-609).
+            f->t2_updates++;
+            if (!f->t2_in_sweep) {
+                launch_gain2_tiles(f, m, m_pad, n_pad, m_on_device);
+                launch_t2_tiles(f, m_pad, n_pad);
+            }
+            if (f->between_joseph) {  // (ekfvio_step_image: the frame's outputs, from mu and the partial sums of K y, in front of the one GEMM)
+                f->hook_kyp_blocks = m_pad / 64;
+                f->between_joseph(f);
+                f->hook_kyp_blocks = 0;
+            }
+            ProfScope ps(f, PC_GEMM_UPDATE, 2.0 * n * (double)n * m_pad, 1);
+            e2.mode = 3;  // the mean takes K y from the gain tiles' partial sums (gain_tile2: Kyp = Wt, one row of sums per block column)
+            e2.Kyp = f->Wt;
+            e2.kyp_blocks = m_pad / 64;
+            e2.kyp_ld = ld;
+            e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: the GEMM writes nothing (T2, K, G' are scratch)
+            launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, f->P2, ld, f->P, ld, 1, 0, &e2);
+        } else {
             if (!f->gain_in_sweep) launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
             // The two P-update GEMMs, back to back (one profiler scope, two launches), both triangles:
             //   T = Sigma - K*(H Sigma)   (I_KH * Sigma, :594) in place; also G and K*y (column n)
@@ -1056,8 +1078,8 @@ int launch_update_gemms_scratch(ekfvio_filter* f, int m, int reps) {
     const int n = f->n, ld = f->ldp;
     const int m_pad = round_up(m > 0 ? m : 1, EKF_TILE);
     GemmEpi e1, e2;
-    if (sweep_supports_schur(f, m_pad)) {
-        // with the Schur sweep the update has ONE P-update GEMM: Sigma' = T2 + K G'^T
+    if (sweep_supports_schur(f, m_pad) || t2_flow_shape(f, m_pad, round_up(n, EKF_TILE))) {
+        // with the Schur sweep, and where T2 comes out of the persistent launch, the update has ONE P-update GEMM: Sigma' = T2 + K G'^T
         e2.mode = 2;
         for (int r = 0; r < reps; r++)
             launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, f->P, ld, f->P2, ld, 1, 0, &e2);

@@ -766,13 +766,20 @@ __global__ void points_kernel(const float* __restrict__ mu, int N, const uint8_t
 __global__ __launch_bounds__(256) void frame_outputs_kernel(const float* __restrict__ mu, int N_old, const int* __restrict__ added_dev,
                                                             const uint8_t* __restrict__ img, int pitch, int w, int h, float fx, float fy,
                                                             float cx, float cy, float* __restrict__ out, const int* __restrict__ info,
-                                                            int* host_word, int seq, const float* __restrict__ Pcol) {
-    extern __shared__ float s_mu[];  // Pcol: the updated mean, EKF_BASE + 3 N floats
+                                                            int* host_word, int seq, const float* __restrict__ Pcol,
+                                                            const float* __restrict__ Kyp = nullptr, int kyp_blocks = 0, int kyp_ld = 0) {
+    extern __shared__ float s_mu[];  // Pcol / Kyp: the updated mean, EKF_BASE + 3 N floats
     const int added = added_dev ? *added_dev : 0;
     const int N = N_old + added;
-    if (Pcol) {
+    if (Pcol || Kyp) {
         const int n = EKF_BASE + 3 * N;
-        for (int e = threadIdx.x; e < n; e += 256) s_mu[e] = mu[e] + Pcol[e];
+        for (int e = threadIdx.x; e < n; e += 256) {
+            if (Kyp) {  // (round 6, T2 flow: K y as the gain tiles' partial sums, one row per block column, added as gemm16_finish_mean<3> adds them)
+                float ky = Kyp[e];
+                for (int cb = 1; cb < kyp_blocks; cb++) ky = ky + Kyp[(size_t)cb * kyp_ld + e];
+                s_mu[e] = mu[e] + ky;
+            } else s_mu[e] = mu[e] + Pcol[e];
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             const float q0 = s_mu[3], q1 = s_mu[4], q2 = s_mu[5], q3 = s_mu[6];
@@ -1400,9 +1407,13 @@ int ekfvio_step_image(ekfvio_filter* f, double stamp, const uint8_t* image, int3
                 float fx, fy, cx, cy;
                 intrinsics(g, fr.K, &fx, &fy, &cx, &cy);
                 g->between_joseph_seq = next_status_seq(g);
+                // (two-GEMM flow: K y is column n of P, left there by the first Joseph GEMM; T2 flow: the gain tiles' partial sums in Wt, and the
+                // outputs go out in front of the update's ONE GEMM)
+                const bool kyp = g->hook_kyp_blocks > 0;
                 hipLaunchKernelGGL(frame_outputs_kernel, dim3(1), dim3(256), sizeof(float) * (size_t)g->n, g->stream, g->mu, g->N, (const int*)nullptr,
                                    fr.img[0] + (size_t)KLT_BORDER * pitch + KLT_BORDER, pitch, fr.w[0], fr.h[0], fx, fy, cx, cy, g->d_out, g->info,
-                                   g->d_hinfo, g->between_joseph_seq, (const float*)(g->P + (size_t)g->n * g->ldp));
+                                   g->d_hinfo, g->between_joseph_seq, kyp ? (const float*)nullptr : (const float*)(g->P + (size_t)g->n * g->ldp),
+                                   kyp ? (const float*)g->Wt : (const float*)nullptr, g->hook_kyp_blocks, g->ldp);
             };
             f->between_joseph_seq = 0;
         }

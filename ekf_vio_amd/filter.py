@@ -235,10 +235,10 @@ class TightlyCoupledEKF:
         return Cc.T.copy()
 
     def counters(self):
-        """ekfvio_get_counters: dict(persistent, schur, recoveries, mode, early_output_frames)."""
+        """ekfvio_get_counters: dict(persistent, schur, recoveries, mode, early_output_frames, t2_updates)."""
         c = (C.c_int64 * 8)()
         self._chk(self.lib.ekfvio_get_counters(self.h, c))
-        return dict(persistent=int(c[0]), schur=int(c[1]), recoveries=int(c[2]), mode=int(c[3]), early_output_frames=int(c[4]))
+        return dict(persistent=int(c[0]), schur=int(c[1]), recoveries=int(c[2]), mode=int(c[3]), early_output_frames=int(c[4]), t2_updates=int(c[5]))
 
     def _need_hooks(self):
         if not self.hooks:

@@ -249,8 +249,10 @@ EKFVIO_API int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, doubl
 /* Diagnostic counters of a handle (no device work): counters[0] Cholesky sweeps that went out as the single persistent launch
  * (chol_persist_kernel; the others took one launch per block step), [1] sweeps with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1),
  * [2] updates run again behind an aborted persistent sweep, [3] the handle's sweep mode now (2: persistent where it applies, 0: one launch
- * per block step), [4] frames of ekfvio_step_image whose outputs and status were published between the update's two Joseph GEMMs,
- * [5..7] reserved (0). */
+ * per block step), [4] frames of ekfvio_step_image whose outputs and status were published in front of the update's last GEMM,
+ * [5] updates whose right Joseph factor T2 = Sigma (I - K H)^T came out of the Cholesky sweep's launch (or the tile kernel that stands in for
+ * it behind a per-step sweep), leaving ONE P-update GEMM behind it (where the fused persistent launch forms the gain: about 65 .. 265
+ * landmarks, all measured), [6..7] reserved (0). */
 EKFVIO_API int ekfvio_get_counters(ekfvio_filter* f, int64_t counters[8]);
 
 #ifdef __cplusplus

@@ -585,11 +585,17 @@ def test_indefinite_matrix_goes_through_the_signed_factorisation(m, npos, shuffl
 
 
 @pytest.mark.parametrize("N", [20, 100, 256])
-def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
-    """Default (EKFVIO_SCHUR=0): the sweep yields Y and L^-T, K = Y L^-1 and T = (I - K H) Sigma are MFMA GEMMs behind it
-    (the reference's order of operations, :580-594), then Sigma' = T + G K^T.  EKFVIO_SCHUR=1: T2 = Sigma (I - K H)^T and
-    K = X A^-1 come out of the sweep itself as Schur tiles, then Sigma' = (I - K H) T2 + K R K^T.  Same Joseph update term
-    for term, other summation order: both must sit within the fp64 yardstick, and close to each other."""
+def test_schur_sweeps_agree_with_the_gemm_formulation(monkeypatch, N):
+    """Three formulations of the same Joseph update (TightlyCoupledEKF.cpp:577-600), term for term, with other summation orders:
+      "gemm"  (EKFVIO_T2=0; rounds 1-5's default, and still every shape the T2 flow does not take): the sweep yields Y and L^-T,
+              K = Y L^-1 and T = (I - K H) Sigma are MFMA products behind it (the reference's order of operations, :580-594), then
+              Sigma' = T + G K^T;
+      "t2"    (round 6's default where the fused persistent launch forms the gain, N = 65 .. ~265 all measured): T2 = Sigma (I - K H)^T
+              is accumulated INSIDE that launch by owners whose tile is finished, the gain tiles leave K, G' = K R^T - (H T2)^T and
+              K y's partial sums, and ONE GEMM is left behind the launch: Sigma' = (I - K H) T2 + K R K^T = T2 + K G'^T;
+      "schur" (EKFVIO_SCHUR=1): T2 and K as Schur tiles of a per-step sweep, joseph_g_kernel, the same one GEMM.
+    All must sit within the fp64 yardstick and close to each other; which path ran is asserted (the flows had once been
+    compared with themselves)."""
     sc = Scenario(N, seed=4)
     o64 = OracleFilter(np.float64)
     uv = sc.initial_features()
@@ -603,31 +609,38 @@ def test_schur_sweep_agrees_with_the_gemm_formulation(monkeypatch, N):
     p = p.copy()
     p[3] = 0
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("EKFVIO_SCHUR", mode)
+    for mode, env in (("schur", {"EKFVIO_SCHUR": "1"}), ("t2", {}), ("gemm", {"EKFVIO_T2": "0"})):
+        for k in ("EKFVIO_SCHUR", "EKFVIO_T2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         g = TightlyCoupledEKF(max_features=N)
         g.set_state(st)
         g.process(sc.dt)
-        if mode == "1":
+        if mode == "schur":
             o64.set_state(g.get_state())
         assert g.updateWithFeaturePositions(z, R, p) == capi.OK
         out[mode] = g.get_state()
-        # which path ran (with the persistent launch the default, EKFVIO_SCHUR=1 alone must still select the Schur sweep)
-        c = g.sweep_counts()
-        assert c["schur"] == (1 if mode == "1" else 0), (mode, c)
-        if mode == "1":
+        c = g.counters()
+        assert c["schur"] == (1 if mode == "schur" else 0), (mode, c)
+        if mode == "schur":
             assert c["persistent"] == 0, c
+        # the T2 flow is a property of the shape: N = 100 and 256 (all but one landmark measured) take it, N = 20 (one block column) does not
+        assert c["t2_updates"] == (1 if mode == "t2" and N >= 100 else 0), (mode, c)
         g.close()
-    assert not np.array_equal(out["1"]["Sigma"], out["0"]["Sigma"])  # two summation orders, not one path compared with itself
+    # the two-GEMM flow's bits differ from the Schur formulations' (two summation orders, not one path compared with itself)
+    assert not np.array_equal(out["schur"]["Sigma"], out["gemm"]["Sigma"])
+    if N >= 100:
+        assert not np.array_equal(out["t2"]["Sigma"], out["gemm"]["Sigma"])
     o32 = OracleFilter(np.float32)
     o32.set_state(o64.get_state())
     o32.update(z, R, p), o64.update(z, R, p)
     s32, s64 = o32.get_state(), o64.get_state()
-    for mode in ("1", "0"):
+    for mode in out:
         assert maxabs(out[mode]["base_mu"], s64["base_mu"]) <= ACC_FACTOR * maxabs(s32["base_mu"], s64["base_mu"]) + MU_FLOOR, mode
         assert relf(out[mode]["Sigma"], s64["Sigma"]) <= ACC_FACTOR * relf(s32["Sigma"], s64["Sigma"]) + SIG_FLOOR, mode
-    assert np.array_equal(out["1"]["last_klt"], out["0"]["last_klt"]) and np.array_equal(out["1"]["del_flag"], out["0"]["del_flag"])
-    assert relf(out["1"]["Sigma"], out["0"]["Sigma"]) < 2e-5 and maxabs(out["1"]["base_mu"], out["0"]["base_mu"]) < 2e-5
+        assert np.array_equal(out[mode]["last_klt"], out["gemm"]["last_klt"]) and np.array_equal(out[mode]["del_flag"], out["gemm"]["del_flag"])
+        assert relf(out[mode]["Sigma"], out["gemm"]["Sigma"]) < 2e-5 and maxabs(out[mode]["base_mu"], out["gemm"]["base_mu"]) < 2e-5, mode
 
 
 @pytest.mark.parametrize("N,fails", [(256, 0), (256, 37), (300, 0), (300, 11), (100, 3), (64, 0), (40, 5), (33, 0), (400, 0), (400, 23)])
