@@ -1221,7 +1221,7 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
     pa.t2_skip = t2_skip_owners(f, m_pad, n_pad);
     pa.t2 = (pa.gain && pa.t2_skip >= 0) ? 1 : 0;
     pa.compact = pa.t2;
-    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = f->P2, pa.ldt = f->ldp, pa.nstate = f->n;
+    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = t2_buffer(f), pa.ldt = f->ldp, pa.nstate = f->n;
     f->t2_in_sweep = pa.t2 != 0;
     pa.dbg = f->sweep_dbg;
     pa.bound.spin_limit = f->sweep_spin_limit > 0 ? f->sweep_spin_limit : SWEEP_SPIN_LIMIT;
@@ -1394,7 +1394,7 @@ void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad) {
     pa.L = f->Laug, pa.ldl = f->ld_aug;
     pa.mb = m_pad / PB, pa.idb0 = m_pad / PB + n_pad / PB;
     pa.Lsign = f->Lsign;
-    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = f->P2, pa.ldt = f->ldp, pa.nstate = f->n;
+    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = t2_buffer(f), pa.ldt = f->ldp, pa.nstate = f->n;
     const int nX = n_pad / PB;
     hipLaunchKernelGGL(t2_tiles_kernel, dim3(nX * (nX + 1) / 2), dim3(256), 0, f->stream, pa);
 }

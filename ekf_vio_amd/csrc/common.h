@@ -336,6 +336,13 @@ int live_handles_on(int device);  // api.hip: handles alive on that device in th
 void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, const float* T = nullptr);  // T: the covariance G' is taken from (null: f->P)
 bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad);  // chol.hip: T2 = Sigma (I - K H)^T comes out of the sweep (or t2_tiles_kernel), ONE Joseph GEMM behind it
 void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad);
+// Where T2 lives between the sweep and the one GEMM behind it: the dense-F buffer, dead during an update in either predict mode (the dense
+// mode rebuilds F at the next process(dt)).  Not f->P2: that is process(dt)'s next output, and with T2 written there by other XCDs moments
+// earlier process(dt) measured 1.4 us longer (EKFVIO_T2_BUF=1 puts it back there, for the A/B).
+inline float* t2_buffer(ekfvio_filter* f) {
+    static const bool in_p2 = getenv("EKFVIO_T2_BUF") && atoi(getenv("EKFVIO_T2_BUF")) == 1;
+    return in_p2 ? f->P2 : f->Fdense;
+}
 void launch_gain2_tiles(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false, bool with_wt = true);
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);

@@ -1055,7 +1055,7 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             e2.kyp_blocks = m_pad / 64;
             e2.kyp_ld = ld;
             e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: the GEMM writes nothing (T2, K, G' are scratch)
-            launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, f->P2, ld, f->P, ld, 1, 0, &e2);
+            launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, t2_buffer(f), ld, f->P, ld, 1, 0, &e2);
         } else {
             if (!f->gain_in_sweep) launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);
             // The two P-update GEMMs, back to back (one profiler scope, two launches), both triangles:

@@ -43,8 +43,14 @@ extern "C" {
 enum {
     EKFVIO_OK = 0,
     EKFVIO_EINVAL = 1,   /* what the reference ROS_ASSERTs (size mismatch, dt < 0, null) */
-    EKFVIO_ENUMERIC = 2, /* Cholesky met a non-positive pivot (reference: ROS_ERROR_COND at
-                            TightlyCoupledEKF.cpp:579, then continues); state is still updated */
+    EKFVIO_ENUMERIC = 2, /* The factorisation of S met a NON-POSITIVE pivot; the state is still updated, through a signed factor
+                            S = U diag(+-1) U^T, as the reference's LDL^T carries a negative pivot along.  STRICTER than the reference's
+                            log line: `ROS_ERROR_COND(solver.info() == Eigen::NumericalIssue, ...)` (TightlyCoupledEKF.cpp:579) fires only
+                            for a pivot that is EXACTLY zero -- Eigen's simplicial LDL^T sets NumericalIssue for `d == 0` alone and then
+                            abandons the factorisation, so what the reference computes behind it (:580) is undefined (it reads D entries
+                            it never wrote); a negative pivot passes there without a word.  Here both are reported with this one code; on
+                            an exactly zero pivot the state behind it is not finite (1 / 0 in the factor), as undefined as upstream's.
+                            (tests/test_oracle_amd_cpu.py, tests/test_gpu_shapes.py: test_exactly_singular_s_*) */
     EKFVIO_ECAPACITY = 3,/* more landmarks than config.max_features */
     EKFVIO_EDEVICE = 4,  /* HIP runtime failure; ekfvio_last_error() has the text */
     EKFVIO_ESTATE = 5,   /* call sequence error (e.g. KLT track before two frames exist) */

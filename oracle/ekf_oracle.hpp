@@ -36,6 +36,8 @@
 #include <cstring>
 #include <vector>
 
+#include "amd_order.hpp"
+
 namespace oracle {
 
 constexpr int BASE = 22;  // TightlyCoupledEKF.h:12 BASE_STATE_SIZE
@@ -61,6 +63,19 @@ struct Config {
     // div_reciprocal = 1: `vector /= scalar` (:198, :214, :243, :277, :293, :309 and normalize()) multiplies by
     //   Scalar(1)/scalar (Eigen <= 3.2.x SelfCwiseBinaryOp.h); 0 (default): a true division (Eigen >= 3.2.90).
     int div_reciprocal = 0;
+    // ldlt_amd_order = 1 (default): SimplicialLDLT's default ordering (AMDOrdering, TightlyCoupledEKF.cpp:577: the solver is declared
+    //   without an ordering argument) -- the matrix factored is S^T(P, P) with P from oracle/amd_order.hpp on the structural pattern
+    //   of S^T's lower triangle (a dense-array restatement has no structure of its own: an entry counts as structural when it is
+    //   non-zero -- Sigma is pruned at :117 / :625, so its exact zeros ARE its structural zeros -- or lies in one of R's 2 x 2
+    //   blocks, whose four entries are inserted whatever their value, :513-519).  For a numerically dense S with m > ~100 rows every
+    //   node is "dense" to AMD and P is the identity; below that, and for the block-diagonal S of an update straight from the
+    //   diagonal prior (test/test_ekf.cpp:66-141), a real minimum-degree permutation runs.  0: natural order (rounds 1-5).
+    int ldlt_amd_order = 1;
+    // amd_keep_diagonal = 1 (default): the pattern AMD sees includes the diagonal (Eigen's Ordering.h has the `prune(keep_diag())`
+    //   that would drop it commented out); 0: textbook cs_amd.  Moves the "every node is dense" threshold between m >= 101 and 103
+    //   and, below it, nothing but tie-breaks.
+    int amd_keep_diagonal = 1;
+    int ldlt_general_path = 0;  // test switch: the sparse-form factorisation loop even where the dense loop applies (same bits, asserted)
 };
 
 // the three arithmetic choices above, passed down to the free functions
@@ -193,7 +208,13 @@ struct Filter {
     std::vector<uint8_t> del_flag; // Feature.h:46
     std::vector<T> Sigma;          // dense column-major n x n
     int n = BASE;
-    int last_update_info = 0;      // 1 if LDLT met a non-positive pivot
+    int last_update_info = 0;      // bit 0: the LDLT met a non-positive pivot (what the HIP path reports as EKFVIO_ENUMERIC);
+                                   // bit 1: a pivot was EXACTLY zero -- the only case in which Eigen's simplicial LDLT sets
+                                   // NumericalIssue (SimplicialCholesky_impl.h: `if(d == RealScalar(0)) { ok = false; break; }`),
+                                   // i.e. the only case in which the reference's ROS_ERROR_COND at :579 fires.  (Eigen then abandons
+                                   // the factorisation and the solve at :580 reads D entries it never wrote: undefined upstream.
+                                   // Here the elimination carries on through the division by zero: non-finite, deterministic.)
+    std::vector<int> last_perm;    // the ordering the last update's LDLT used (P[k] = measurement row of the k-th pivot)
 
     // emulation of the function-static cache in convolveFeature (:400-403)
     T cache_om[3] = {0, 0, 0};
@@ -462,8 +483,8 @@ struct Filter {
     }
 
     // TightlyCoupledEKF.cpp:475-628.  z: 2 per landmark, R: 4 per landmark (col-major
-    // 2x2), pass: 1 per landmark.  Returns 0, or 1 when the LDLT hit a pivot <= 0
-    // (reference: ROS_ERROR_COND and continue).
+    // 2x2), pass: 1 per landmark.  Returns last_update_info: bit 0 = the LDLT met a pivot <= 0 (the reference says
+    // nothing and continues), bit 1 = a pivot exactly zero (the reference: ROS_ERROR_COND at :579, then continues).
     int update(const T* z_in, const T* R_in, const uint8_t* pass) {
         const int N = num_features();
         std::vector<int> idx;
@@ -507,23 +528,111 @@ struct Filter {
         std::vector<T> Sm((size_t)m * m);
         for (int c = 0; c < m; c++)
             for (int r = 0; r < m; r++) Sm[(size_t)c * m + r] = S(idx[r], idx[c]) + Rm[(size_t)c * m + r];
-        // SimplicialLDLT(S^T): up-looking LDL^T of the lower triangle of S^T, restated dense
-        // and without the fill-reducing permutation.  Lr is row-major: Lr[r*m+c] = L(r,c).
-        std::vector<T> Lr((size_t)m * m, T(0)), D(m), yrow(m);
-        for (int r = 0; r < m; r++) {
-            T d = Sm[(size_t)r * m + r];
-            for (int c = 0; c < r; c++) {
-                T yc = Sm[(size_t)r * m + c];  // S^T(r,c) = S(c,r)
-                const T* lc = &Lr[(size_t)c * m];
-                for (int k = 0; k < c; k++) yc -= lc[k] * yrow[k];
-                yrow[c] = yc;
-                T l = yc / D[c];
-                Lr[(size_t)r * m + c] = l;
-                d -= l * yc;
+        // SimplicialLDLT(S^T): up-looking LDL^T of the lower triangle of S^T -- i.e. of S's UPPER triangle, mirrored -- restated
+        // dense.  Lr is row-major: Lr[r*m+c] = L(r,c), in the PERMUTED numbering when an ordering applies.
+        std::vector<int> perm(m);
+        for (int r = 0; r < m; r++) perm[r] = r;
+        bool natural = true, dense_pattern = true;
+        std::vector<int> cp, ri;  // structural pattern of the symmetric matrix (full, rows ascending per column)
+        if (cfg.ldlt_amd_order) {
+            // structural(r,c), r <= c: S(r,c) != 0, or the diagonal, or inside one of R's 2 x 2 blocks (rows 2j, 2j+1)
+            auto structural = [&](int r, int c) {
+                const int lo = r < c ? r : c, hi = r < c ? c : r;
+                return lo == hi || (lo >> 1) == (hi >> 1) || Sm[(size_t)hi * m + lo] != T(0);
+            };
+            cp.assign(m + 1, 0);
+            for (int c = 0; c < m; c++) {
+                cp[c] = (int)ri.size();
+                for (int r = 0; r < m; r++)
+                    if (structural(r, c)) ri.push_back(r);
+                    else dense_pattern = false;
             }
-            D[r] = d;
-            Lr[(size_t)r * m + r] = T(1);
-            if (!(d > T(0))) last_update_info = 1;
+            cp[m] = (int)ri.size();
+            perm = ekf_oracle::amd_order(m, cp, ri, cfg.amd_keep_diagonal != 0);
+            for (int r = 0; r < m; r++) natural = natural && perm[r] == r;
+        }
+        last_perm = perm;
+        std::vector<T> Lr((size_t)m * m, T(0)), D(m), yrow(m);
+        if (natural && dense_pattern && !cfg.ldlt_general_path) {
+            for (int r = 0; r < m; r++) {
+                T d = Sm[(size_t)r * m + r];
+                for (int c = 0; c < r; c++) {
+                    T yc = Sm[(size_t)r * m + c];  // S^T(r,c) = S(c,r)
+                    const T* lc = &Lr[(size_t)c * m];
+                    for (int k = 0; k < c; k++) yc -= lc[k] * yrow[k];
+                    yrow[c] = yc;
+                    T l = yc / D[c];
+                    Lr[(size_t)r * m + c] = l;
+                    d -= l * yc;
+                }
+                D[r] = d;
+                Lr[(size_t)r * m + r] = T(1);
+                if (!(d > T(0))) last_update_info |= 1;
+                if (d == T(0)) last_update_info |= 2;
+            }
+        } else {
+            // The general form, as SimplicialCholesky_impl.h's analyzePattern_preordered / factorize_preordered run it on
+            // ap = upper triangle of S^T(P, P): elimination tree, then row k of L from the entries of column k of ap (ascending row
+            // index), its pattern gathered along the tree in topological order, one sparse triangular solve per row.  On a dense
+            // pattern in natural order this visits 0 .. k-1 ascending: the loop above, bit for bit (tests/test_oracle_amd_cpu.py).
+            auto apv = [&](int i, int k) {  // ap(i,k), i <= k: S's upper triangle at the permuted pair
+                const int a = perm[i], b = perm[k];
+                return a <= b ? Sm[(size_t)b * m + a] : Sm[(size_t)a * m + b];
+            };
+            auto in_ap = [&](int i, int k) {
+                if (!cfg.ldlt_amd_order) return true;
+                const int a = perm[i], b = perm[k];
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                return lo == hi || (lo >> 1) == (hi >> 1) || Sm[(size_t)hi * m + lo] != T(0);
+            };
+            std::vector<int> parent(m, -1), tags(m, -1), pattern(m);
+            for (int k = 0; k < m; k++) {  // elimination tree
+                parent[k] = -1;
+                tags[k] = k;
+                for (int i0 = 0; i0 < k; i0++) {
+                    if (!in_ap(i0, k)) continue;
+                    for (int i = i0; tags[i] != k; i = parent[i]) {
+                        if (parent[i] == -1) parent[i] = k;
+                        tags[i] = k;
+                    }
+                }
+            }
+            std::vector<std::vector<int>> Lrow(m);
+            std::vector<std::vector<T>> Lval(m);
+            std::vector<T> y(m, T(0));
+            std::fill(tags.begin(), tags.end(), -1);
+            for (int k = 0; k < m; k++) {
+                y[k] = T(0);
+                int top = m;
+                tags[k] = k;
+                for (int i0 = 0; i0 <= k; i0++) {
+                    if (!in_ap(i0, k)) continue;
+                    y[i0] += apv(i0, k);
+                    int len = 0;
+                    for (int i = i0; tags[i] != k; i = parent[i]) {
+                        pattern[len++] = i;
+                        tags[i] = k;
+                    }
+                    while (len > 0) pattern[--top] = pattern[--len];
+                }
+                T d = y[k];
+                y[k] = T(0);
+                for (; top < m; ++top) {
+                    const int i = pattern[top];
+                    const T yi = y[i];
+                    y[i] = T(0);
+                    const T l_ki = yi / D[i];
+                    for (size_t q = 0; q < Lrow[i].size(); q++) y[Lrow[i][q]] -= Lval[i][q] * yi;
+                    d -= l_ki * yi;
+                    Lrow[i].push_back(k);
+                    Lval[i].push_back(l_ki);
+                    Lr[(size_t)k * m + i] = l_ki;
+                }
+                D[k] = d;
+                Lr[(size_t)k * m + k] = T(1);
+                if (!(d > T(0))) last_update_info |= 1;
+                if (d == T(0)) last_update_info |= 2;
+            }
         }
         std::vector<T> Lc((size_t)m * m);  // column-major copy: Lc[c*m+r] = L(r,c)
         for (int r = 0; r < m; r++)
@@ -535,7 +644,7 @@ struct Filter {
             std::vector<T> rhs(m);
 #pragma omp for schedule(static)
             for (int i = 0; i < n; i++) {
-                for (int r = 0; r < m; r++) rhs[r] = Sigma[(size_t)idx[r] * n + i];  // (Sigma*H^T)(i,r)
+                for (int r = 0; r < m; r++) rhs[r] = Sigma[(size_t)idx[perm[r]] * n + i];  // (Sigma*H^T)(i, P[r]): dest = m_P * b
                 for (int r = 0; r < m; r++) {                                          // L w = rhs
                     T v = rhs[r];
                     const T* lr = &Lr[(size_t)r * m];
@@ -549,7 +658,7 @@ struct Filter {
                     for (int k = r + 1; k < m; k++) v -= lc[k] * rhs[k];
                     rhs[r] = v;
                 }
-                for (int r = 0; r < m; r++) K[(size_t)r * n + i] = rhs[r];
+                for (int r = 0; r < m; r++) K[(size_t)perm[r] * n + i] = rhs[r];  // dest = m_Pinv * dest
             }
         }
         prune(K);  // .sparseView(SPARSE_THRESH, SPARSE_EPS)

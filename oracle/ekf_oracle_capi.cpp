@@ -26,6 +26,20 @@ using oracle::BASE;
         if (trig_float >= 0) f->cfg.trig_float = trig_float;                                               \
         if (div_reciprocal >= 0) f->cfg.div_reciprocal = div_reciprocal;                                   \
     }                                                                                                      \
+    /* the LDLT's ordering: -1 leaves a switch as it is */                                                  \
+    extern "C" void P##_set_ldlt_order(void* h, int amd_order, int keep_diagonal, int general_path) {      \
+        auto* f = (oracle::Filter<T>*)h;                                                                   \
+        if (amd_order >= 0) f->cfg.ldlt_amd_order = amd_order;                                             \
+        if (keep_diagonal >= 0) f->cfg.amd_keep_diagonal = keep_diagonal;                                  \
+        if (general_path >= 0) f->cfg.ldlt_general_path = general_path;                                    \
+    }                                                                                                      \
+    /* the ordering the last update used: P[k] = measurement row of the k-th pivot; returns its length */  \
+    extern "C" int P##_last_perm(void* h, int* out, int cap) {                                             \
+        auto* f = (oracle::Filter<T>*)h;                                                                   \
+        const int m = (int)f->last_perm.size();                                                            \
+        for (int i = 0; i < m && i < cap; i++) out[i] = f->last_perm[i];                                   \
+        return m;                                                                                          \
+    }                                                                                                      \
     extern "C" int P##_num_features(void* h) { return ((oracle::Filter<T>*)h)->num_features(); }           \
     extern "C" int P##_dim(void* h) { return ((oracle::Filter<T>*)h)->n; }                                 \
     extern "C" void P##_add_features(void* h, const T* uv, int k) {                                        \
@@ -114,4 +128,11 @@ extern "C" int orc_max_threads() {
 #else
     return 1;
 #endif
+}
+
+// The ordering alone, for tests/test_oracle_amd_cpu.py: pattern in compressed-column form (rows ascending per column).
+extern "C" void orc_amd_order(int n, const int* col_ptr, const int* row_idx, int keep_diagonal, int* perm_out) {
+    std::vector<int> cp(col_ptr, col_ptr + n + 1), ri(row_idx, row_idx + col_ptr[n]);
+    const std::vector<int> p = ekf_oracle::amd_order(n, cp, ri, keep_diagonal != 0);
+    for (int i = 0; i < n; i++) perm_out[i] = p[i];
 }

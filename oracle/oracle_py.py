@@ -18,7 +18,7 @@ BASE = 22
 
 def build_oracle(force=False):
     """Compile the oracle with g++ (make -C oracle)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.hpp", "ekf_oracle_capi.cpp", "klt_oracle.cpp", "fast_oracle.cpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.hpp", "amd_order.hpp", "ekf_oracle_capi.cpp", "klt_oracle.cpp", "fast_oracle.cpp", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -99,13 +99,14 @@ class OracleFilter:
     precision; np.float64 is the yardstick."""
 
     def __init__(self, dtype=np.float32, depth=0.5, depth_var=100.0, homog_var=1e-5, emulate_static_cache=True,
-                 eigen_sse_quat=None, trig_float=None, div_reciprocal=None):
+                 eigen_sse_quat=None, trig_float=None, div_reciprocal=None, ldlt_amd_order=None, amd_keep_diagonal=None):
         self.lib = oracle_lib()
         self.dtype = np.dtype(dtype)
         self.pre = "orc32" if self.dtype == np.float32 else "orc64"
         self.ct = C.c_float if self.dtype == np.float32 else C.c_double
         self.h = C.c_void_p(self._f("create")(depth, depth_var, homog_var, int(bool(emulate_static_cache))))
         self.set_variant(eigen_sse_quat, trig_float, div_reciprocal)
+        self.set_ldlt_order(ldlt_amd_order, amd_keep_diagonal)
 
     def _f(self, name):
         return getattr(self.lib, self.pre + "_" + name)
@@ -116,6 +117,25 @@ class OracleFilter:
         None leaves a switch unchanged."""
         enc = lambda v: -1 if v is None else int(bool(v))
         self._f("set_variant")(self.h, enc(eigen_sse_quat), enc(trig_float), enc(div_reciprocal))
+
+    def set_ldlt_order(self, ldlt_amd_order=None, amd_keep_diagonal=None, general_path=None):
+        """SimplicialLDLT's ordering (ekf_oracle.hpp Config): Eigen's default AMD ordering on S's structural pattern (default on;
+        off = natural order, rounds 1-5), with the diagonal in the pattern as Eigen hands it over (default on).  None: unchanged."""
+        enc = lambda v: -1 if v is None else int(bool(v))
+        fn = self._f("set_ldlt_order")
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        fn.restype = None
+        fn(self.h, enc(ldlt_amd_order), enc(amd_keep_diagonal), enc(general_path))
+
+    def last_perm(self):
+        """The ordering the last update's LDLT used: P[k] = measurement row of the k-th pivot."""
+        fn = self._f("last_perm")
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        fn.restype = C.c_int
+        m = fn(self.h, None, 0)
+        out = np.zeros(max(m, 1), np.int32)
+        fn(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), m)
+        return out[:m]
 
     def close(self):
         if self.h:
@@ -344,3 +364,23 @@ def replenish(img, existing_px, num_features, threshold=50, min_dist=30, kill_pa
     n = oracle_lib().orc_replenish(_p(img, C.c_uint8), w, h, w, _p(ex, C.c_float), ex.shape[0], int(num_features),
                                    int(threshold), int(min_dist), int(kill_pad), cap, out.ctypes.data_as(C.POINTER(C.c_int)))
     return out[:n].copy()
+
+
+def amd_order(pattern, keep_diagonal=True):
+    """oracle/amd_order.hpp on a boolean (n, n) pattern (symmetrised here): P with P[k] = the k-th pivot's index."""
+    a = np.asarray(pattern, bool)
+    a = a | a.T
+    n = a.shape[0]
+    cp = np.zeros(n + 1, np.int32)
+    rows = []
+    for j in range(n):
+        r = np.nonzero(a[:, j])[0]
+        rows.append(r)
+        cp[j + 1] = cp[j] + len(r)
+    ri = np.ascontiguousarray(np.concatenate(rows) if n and cp[n] else np.zeros(0), np.int32)
+    out = np.zeros(max(n, 1), np.int32)
+    fn = oracle_lib().orc_amd_order
+    fn.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    fn.restype = None
+    fn(n, cp.ctypes.data_as(C.POINTER(C.c_int)), ri.ctypes.data_as(C.POINTER(C.c_int)), int(bool(keep_diagonal)), out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out[:n]

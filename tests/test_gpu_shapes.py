@@ -302,3 +302,34 @@ def test_n1024_from_the_raw_prior_survives_an_indefinite_innovation_covariance(o
             checked = True
     assert flagged >= 1 and checked  # otherwise this test does not exercise what it is named for
     g.close()
+
+
+@pytest.mark.parametrize("N", [3, 100])
+def test_exactly_singular_s_is_flagged_and_never_hangs(N):
+    """VERDICT r05 #4b.  The reference's ROS_ERROR_COND (TightlyCoupledEKF.cpp:579) fires only when Eigen's LDL^T meets a pivot that is
+    EXACTLY zero; the factorisation is then abandoned and what follows upstream is undefined.  S = 0 exactly (zero prior on the measured
+    coordinates, zero measurement noise): the oracle reports both status bits; the HIP path returns EKFVIO_ENUMERIC -- the same code a
+    merely negative pivot gets (include/ekfvio.h: the stricter of the two) -- from every launch shape, without hanging and without
+    touching the bookkeeping; the handle stays usable.  (The covariance behind such an update is not finite, here as upstream.)"""
+    sc = Scenario(N, seed=3)
+    uv = sc.initial_features()
+    z, R, p = list(sc.frames(1))[0]
+    o = OracleFilter(np.float32)
+    o.add_new_features(uv)
+    st = o.get_state()
+    st0 = {**st, "Sigma": np.zeros_like(st["Sigma"])}
+    o.set_state(st0)
+    with np.errstate(all="ignore"):
+        info = o.update(z, np.zeros_like(R), p)
+    assert info & 2 and info & 1, info
+    g = TightlyCoupledEKF(max_features=N)
+    g.set_state(st0)
+    assert g.updateWithFeaturePositions(z, np.zeros_like(R), p) == capi.ENUMERIC
+    got = g.get_state()
+    assert np.array_equal(got["last_klt"], o.get_state()["last_klt"]) and np.array_equal(got["del_flag"], o.get_state()["del_flag"])
+    # the handle is usable afterwards: a regular state, a regular update
+    g.set_state(st)
+    g.process(sc.dt)
+    assert g.updateWithFeaturePositions(z, R, p) in (capi.OK, capi.ENUMERIC)
+    assert np.isfinite(g.get_state()["Sigma"]).all()
+    g.close(), o.close()
