@@ -11,7 +11,7 @@ data path) and value = total steps/s over all ranks.  Launched under torchrun th
 from the environment; launched plainly (`python bench.py --gpus N`) the script starts its N
 ranks itself, before anything in the parent touches a GPU.
 
-Prints ONE JSON line (rank 0).  Besides the contract keys: `roofline` (the P-update GEMM pair),
+Prints ONE JSON line (rank 0).  Besides the contract keys: `roofline` (the P-update GEMM: one launch per step since round 6, a pair before),
 `roofline_step` (the whole step), `cpu_baseline` (fp32 oracle, 1 core), `full_loop` (frames/s of
 ekfvio_step_image: image in, KLT supplies z, update, replenishment), `klt` and `klt_cpu_baseline`.
 """
@@ -390,16 +390,23 @@ def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="struc
     return out
 
 
-def step_flops(N):
-    """Algorithmic flops the step executes (dense form of the update, structured predict), DESIGN.md section 4."""
+def step_flops(N, t2_flow=False):
+    """Algorithmic flops the step executes (dense form of the update, structured predict), DESIGN.md section 4.  t2_flow (round 6, where the fused
+    persistent launch forms the gain): T2 = Sigma - Y S Y^T inside that launch as tile pairs (the product is symmetric: n^2 m), the gain tiles'
+    own copy of T2's measured rows (2 n m^2), and ONE Joseph GEMM behind the launch instead of two."""
     n, m = 22 + 3 * N, 2 * N
     m_pad = ((m + 63) // 64) * 64
-    joseph = 2.0 * n * (n + 1) * m_pad + 2.0 * n * n * m_pad      # T = Sigma - K W (+ the K*y column); Sigma' = T + G K^T
+    if t2_flow:
+        joseph = 2.0 * n * n * m_pad                               # Sigma' = T2 + K G'^T
+        in_launch = 1.0 * n * n * m_pad + 2.0 * n * m_pad * m_pad  # T2's tile pairs; (H T2)^T in the gain tiles
+    else:
+        joseph = 2.0 * n * (n + 1) * m_pad + 2.0 * n * n * m_pad   # T = Sigma - K W (+ the K*y column); Sigma' = T + G K^T
+        in_launch = 0.0
     gain = 1.0 * n * m_pad * m_pad                               # K = Y L^-1, triangular operand
     sweep = m_pad ** 3 / 3.0 + (n + m_pad / 2.0) * m_pad * m_pad  # Cholesky + the two augmented row blocks
     predict = 4.0 * n * (358.0 + 36.0 * N)
-    return {"joseph_gemms": joseph, "gain_gemm": gain, "cholesky_sweep": sweep, "structured_predict": predict,
-            "total": joseph + gain + sweep + predict,
+    return {"joseph_gemms": joseph, "gain_gemm": gain, "t2_in_launch": in_launch, "cholesky_sweep": sweep, "structured_predict": predict,
+            "total": joseph + gain + in_launch + sweep + predict,
             "north_star_dense_form": 4.0 * n ** 3 + m ** 3 / 3.0 + 4.0 * n * m * m + 4.0 * n * n * m}
 
 
@@ -414,6 +421,9 @@ def main():
     ap.add_argument("--no-full-loop", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto ~10-30 s)")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--replay-only", action="store_true",
+                    help="for rocprofv3 --kernel-trace --stats: nothing but warm-up and the timed region's graph replays runs (no eager per-stage pass, no "
+                         "per-call loop, no GEMM micro-replay), so the per-kernel means are those of replayed steps and sum to ms_per_step")
     ap.add_argument("--selftest-dist", action="store_true")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -493,7 +503,10 @@ def main():
              "parity": "oracle unpinned against the reference binary (the reference holds one KAT, test/test_ekf.cpp:44-63; "
                        "no Eigen/ROS/OpenCV in the image to build it): HIP vs own fp32/fp64 CPU restatement, tests/ -m gpu",
              "cpu_baseline_eigen_sparse": "unavailable: no Eigen3 on this box (BASELINE.md B3)"}
-    if rank == 0:
+    if rank == 0 and args.replay_only:
+        extra["replay_only"] = True
+        extra["t2_updates"] = g.counters()["t2_updates"]
+    elif rank == 0:
         # per-kernel-class device time with HIP events on the handle's stream
         g.profile(True)
         g.run_uploaded(total, args.profile_steps, dt)
@@ -507,14 +520,17 @@ def main():
         # the timed region (the per-class event brackets above run eagerly and include host launch gaps).
         avg_us, flops_per_launch = g.profile_update_gemms(50)
         achieved = flops_per_launch / (avg_us * 1e-6) / 1e12
-        extra["roofline"] = {"bound": "mfma", "kernel": "P-update GEMM pair (Sigma - K W, T + G K^T), tile kernel chosen by shape",
+        t2_flow = g.counters()["t2_updates"] > 0  # round 6: ONE P-update GEMM behind the persistent launch, which forms T2 = Sigma (I - K H)^T itself
+        extra["roofline"] = {"bound": "mfma", "kernel": ("the P-update GEMM (Sigma' = T2 + K G'^T; T2 and G' come out of the persistent launch), tile kernel chosen by shape" if t2_flow
+                                                         else "P-update GEMM pair (Sigma - K W, T + G K^T), tile kernel chosen by shape"),
+                             "p_update_gemm_launches_per_step": 1 if t2_flow else 2,
                              "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                              "flops_per_launch": flops_per_launch, "avg_launch_us": avg_us,
                              "shape": {"M": n, "N": n, "K": m_pad}}
         # HBM-side traffic and MFMA-busy counters of the same kernels come from separate rocprofv3 --pmc passes
         # (bench.py cannot collect PMCs itself); the committed summaries are quoted when the workload matches
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in (("r06",) if t2_flow else ("r05", "r04", "r03", "r02", "r01")):
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_n256.json" % tag)
             if N == 256 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
@@ -524,7 +540,7 @@ def main():
                     extra["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic_n256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)" % tag
                     extra["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
                     break
-        for tag in ("r05", "r04", "r03", "r02"):
+        for tag in (("r06",) if t2_flow else ("r05", "r04", "r03", "r02")):
             mf = os.path.join(ROOT, "profiles", "%s_pmc_mfma_n256.json" % tag)
             if N == 256 and os.path.exists(mf):
                 mj = json.load(open(mf))
@@ -533,9 +549,9 @@ def main():
                 extra["roofline"]["mfma_counters_source"] = "profiles/%s_pmc_mfma_n256.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...)" % tag
                 break
         # The whole step against the same peak: what fraction of the chip's fp32 matrix rate one filter step uses
-        fl = step_flops(N)
+        fl = step_flops(N, t2_flow)
         ms_step = 1e3 * elapsed / args.steps
-        extra["roofline_step"] = {"bound": "mfma", "flops_per_step": fl["total"], "breakdown": {k: fl[k] for k in ("joseph_gemms", "gain_gemm", "cholesky_sweep", "structured_predict")},
+        extra["roofline_step"] = {"bound": "mfma", "flops_per_step": fl["total"], "breakdown": {k: fl[k] for k in ("joseph_gemms", "gain_gemm", "t2_in_launch", "cholesky_sweep", "structured_predict")},
                                   "achieved": fl["total"] / (ms_step * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": fl["total"] / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                   "north_star_dense_form_flops": fl["north_star_dense_form"],
@@ -586,15 +602,16 @@ def main():
             us_sweep = extra["stage_us_per_step"]["cholesky"]
             extra["roofline_sweep"] = {"bound": "latency (sequential pivot chain of one workgroup; DESIGN.md section 3)",
                                        "kernel": "gather + Cholesky sweep + gain tiles in one persistent launch (chol_persist_kernel where it applies, else gather, one launch per block step, gain kernel)",
-                                       "flops_per_step": fl["cholesky_sweep"] + fl["gain_gemm"], "flops_breakdown": {"cholesky_sweep": fl["cholesky_sweep"], "gain": fl["gain_gemm"]},
+                                       "flops_per_step": fl["cholesky_sweep"] + fl["gain_gemm"] + fl["t2_in_launch"],
+                                       "flops_breakdown": {"cholesky_sweep": fl["cholesky_sweep"], "gain": fl["gain_gemm"], "t2_and_its_measured_rows": fl["t2_in_launch"]},
                                        "stage_us": us_sweep,
-                                       "achieved": (fl["cholesky_sweep"] + fl["gain_gemm"]) / (us_sweep * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": (fl["cholesky_sweep"] + fl["gain_gemm"]) / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       "achieved": (fl["cholesky_sweep"] + fl["gain_gemm"] + fl["t2_in_launch"]) / (us_sweep * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": (fl["cholesky_sweep"] + fl["gain_gemm"] + fl["t2_in_launch"]) / (us_sweep * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                        "note": "event-bracketed stage time of the eager, per-stage timed run (includes a few us of launch gaps); "
-                                               "since round 4 the stage is ONE launch that also holds the measurement gather, the first diagonal tile and the gain's tiles "
-                                               "(chol_persist_kernel, fused); in-kernel stamps: profiles/r05_cholesky_phase_stamps.txt"}
+                                               "since round 4 the stage is ONE launch that also holds the measurement gather, the first diagonal tile and the gain's tiles, "
+                                               "since round 6 also T2 = Sigma (I - K H)^T, G' and K y (chol_persist_kernel, fused); in-kernel stamps: profiles/r06_persistent_t2.txt"}
     g.close()
-    if rank == 0 and world == 1 and not args.no_full_loop:
+    if rank == 0 and world == 1 and not args.no_full_loop and not args.replay_only:
         try:
             extra["concurrent_sequences_one_gpu"] = [concurrent_sequences(N, local, b, min(args.steps, 200)) for b in (2, 4, 8)]
         except Exception as ex:  # an extra, never fatal
@@ -620,6 +637,17 @@ def main():
                         del os.environ["EKFVIO_SWEEP"]
                     else:
                         os.environ["EKFVIO_SWEEP"] = prev_sweep
+                # round 6's same-run A/B: the two-GEMM flow of rounds 1-5 (EKFVIO_T2=0: gain inside the persistent launch, T = Sigma - K W and
+                # Sigma' = T + G K^T as two GEMMs behind it) against the default T2 flow timed as `value` above
+                prev_t2 = os.environ.get("EKFVIO_T2")
+                os.environ["EKFVIO_T2"] = "0"
+                try:
+                    extra["two_gemm_flow_n256"] = device_resident_rate(N, local)
+                finally:
+                    if prev_t2 is None:
+                        del os.environ["EKFVIO_T2"]
+                    else:
+                        os.environ["EKFVIO_T2"] = prev_t2
             except Exception as ex:
                 extra["other_sizes"] = {"error": repr(ex)}
             try:

@@ -38,8 +38,7 @@ for k, c in per.items():
         e["mfma_busy_frac_of_simd_time"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * clk_ghz * dur)
         e["mfma_busy_frac_at_2p4ghz"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * 2.4 * dur)
     out["kernels"][k] = e
-gem = {k: v for k, v in out["kernels"].items() if k.startswith("void gemm16_kernel<48, 2, 1>") or k.startswith("void gemm16_kernel<48, 2, 2>")
-       or k.startswith("gemm16_kernel<48, 2, 1>") or k.startswith("gemm16_kernel<48, 2, 2>")}
+gem = {k: v for k, v in out["kernels"].items() if any(("gemm16_kernel<48, 2, %d>" % e) in k for e in (1, 2, 3)) and v.get("launches", 0) >= 40}
 if gem:
     out["p_update_gemms"] = {k: {n: v.get(n) for n in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "duration_ns",
                                                         "effective_clock_ghz", "mfma_busy_frac_of_simd_time", "mfma_busy_frac_at_2p4ghz")}

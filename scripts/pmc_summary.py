@@ -30,8 +30,14 @@ for k, d in out["kernels"].items():
         d["fetch_bytes_corrected"] = 2 * 1024 * d["FETCH_SIZE_KiB_mean"]
     if "WRITE_SIZE_KiB_mean" in d:
         d["write_bytes"] = 1024 * d["WRITE_SIZE_KiB_mean"]
+# round 6: ONE P-update GEMM per step (Sigma' = T2 + K G'^T, EPI 3) where the persistent launch forms T2; before: the pair (EPI 1, EPI 2)
+one = [v for k, v in out["kernels"].items() if "gemm16_kernel<48, 2, 3>" in k and v.get("launches_fetch", 0) >= 40]
 jos = [v for k, v in out["kernels"].items() if "gemm16_kernel<48, 2, 1>" in k or "gemm16_kernel<48, 2, 2>" in k]
-if len(jos) == 2:
+if len(one) == 1:
+    out["p_update_gemm_traffic_bytes_per_launch"] = one[0]["fetch_bytes_corrected"] + one[0]["write_bytes"]
+    out["p_update_gemm_algorithmic_bytes_per_launch"] = 4 * (2 * 790 * 512 + 2 * 790 * 790)
+    out["p_update_gemm"] = "gemm16_kernel<48, 2, 3>: Sigma' = T2 + K G'^T, one launch per step (T2 flow)"
+elif len(jos) == 2:
     out["p_update_gemm_traffic_bytes_per_launch"] = 0.5 * sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in jos)
     out["p_update_gemm_algorithmic_bytes_per_launch"] = 4 * (2 * 790 * 512 + 2 * 790 * 790)
 dst = os.path.join(root, "profiles", "%s_pmc_traffic_n256.json" % name)
