@@ -8,6 +8,8 @@
 #include <atomic>
 #include <chrono>
 
+#include <unistd.h>
+
 #include "common.h"
 
 #define HIPC(f, expr)                                                                              \
@@ -293,8 +295,28 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
 // launches from different handles' streams can each get part of the compute units and wait for workgroups the other one
 // keeps out (every wait is bounded, but that ends in an aborted update, not in a result).  It is therefore used only by
 // a device's sole handle; with several handles on a device every one of them takes one launch per block step.
-static std::atomic<int> g_live_handles[64];
-int live_handles_on(int device) { return (device >= 0 && device < 64) ? g_live_handles[device].load(std::memory_order_relaxed) : 2; }
+// Live handles per device, PROCESS-wide: the product library and the hooks build of the same sources can be loaded into one
+// process (the tests do; a node that links one and dlopens a tool built on the other could), each with its own statics -- two copies of a
+// per-library count would each see a "sole handle" and let two persistent launches loose on one device.  The first copy to need the
+// registry allocates it and leaves its address in the process environment under a name that carries the pid (so a forked child's or an
+// exec'ed program's copy of the variable is ignored); every later copy picks it up there.  No exported symbol, no file.
+static std::atomic<int>* live_registry() {
+    static std::atomic<int>* reg = [] {
+        char name[64], val[32];
+        snprintf(name, sizeof(name), "EKFVIO_LIVE_HANDLES_%ld", (long)getpid());
+        if (const char* e = getenv(name)) {
+            void* p = nullptr;
+            if (sscanf(e, "%p", &p) == 1 && p) return static_cast<std::atomic<int>*>(p);
+        }
+        auto* a = new std::atomic<int>[64];
+        for (int i = 0; i < 64; i++) a[i].store(0, std::memory_order_relaxed);
+        snprintf(val, sizeof(val), "%p", static_cast<void*>(a));
+        setenv(name, val, 1);
+        return a;
+    }();
+    return reg;
+}
+int live_handles_on(int device) { return (device >= 0 && device < 64) ? live_registry()[device].load(std::memory_order_relaxed) : 2; }
 
 extern "C" {
 
@@ -307,7 +329,7 @@ int ekfvio_create(const ekfvio_config* cfg, int device, void* stream, ekfvio_fil
     ekfvio_filter* f = new ekfvio_filter();
     f->cfg = *cfg;
     f->device = device;
-    if (device < 64) g_live_handles[device].fetch_add(1, std::memory_order_relaxed);
+    if (device < 64) live_registry()[device].fetch_add(1, std::memory_order_relaxed);
     const int rc = create_body(f, cfg, device, stream);
     if (rc != EKFVIO_OK) {
         // a half-built handle never leaves the library: whatever was allocated is released here
@@ -338,7 +360,7 @@ int ekfvio_destroy(ekfvio_filter* f) {
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
-    if (f->device >= 0 && f->device < 64) g_live_handles[f->device].fetch_sub(1, std::memory_order_relaxed);
+    if (f->device >= 0 && f->device < 64) live_registry()[f->device].fetch_sub(1, std::memory_order_relaxed);
     delete f;
     return EKFVIO_OK;
 }

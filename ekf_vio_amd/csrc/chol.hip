@@ -1177,9 +1177,7 @@ static int t2_skip_owners(const ekfvio_filter* f, int m_pad, int n_pad) {
     const int mb = m_pad / PB, nX = n_pad / PB;
     const int H = persist_helpers(mb, nX, true), gw = mb * (f->ldp / 64);
     if (1 + gw + H > f->num_cus) return -1;  // the compact launch (chol_persist.inc): every workgroup has its compute unit from the start
-    static const int skip_env = getenv("EKFVIO_T2_SKIP") ? atoi(getenv("EKFVIO_T2_SKIP")) : -1;  // (experiment knob)
-    const int skip = skip_env >= 0 ? skip_env : 0;
-    return (nX * (nX + 1) / 2 <= H - skip) ? skip : -1;
+    return (nX * (nX + 1) / 2 <= H) ? 0 : -1;
 }
 bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad) { return t2_skip_owners(f, m_pad, n_pad) >= 0; }
 bool sweep_is_persistent(const ekfvio_filter* f, int m_pad, int n_pad) {

@@ -338,11 +338,8 @@ bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad);  // chol.hip: 
 void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad);
 // Where T2 lives between the sweep and the one GEMM behind it: the dense-F buffer, dead during an update in either predict mode (the dense
 // mode rebuilds F at the next process(dt)).  Not f->P2: that is process(dt)'s next output, and with T2 written there by other XCDs moments
-// earlier process(dt) measured 1.4 us longer (EKFVIO_T2_BUF=1 puts it back there, for the A/B).
-inline float* t2_buffer(ekfvio_filter* f) {
-    static const bool in_p2 = getenv("EKFVIO_T2_BUF") && atoi(getenv("EKFVIO_T2_BUF")) == 1;
-    return in_p2 ? f->P2 : f->Fdense;
-}
+// earlier process(dt) measured 0.6 us longer (same-box rocprofv3: 9.51 against 8.90 us).
+inline float* t2_buffer(ekfvio_filter* f) { return f->Fdense; }
 void launch_gain2_tiles(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device);
 void launch_gather_potrf(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device = false, bool with_wt = true);
 void launch_potrf_stamps(ekfvio_filter* f, const float* S, int ld, float* L, float* Linv, long long* d_stamps);

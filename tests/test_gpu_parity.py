@@ -770,6 +770,29 @@ def test_persistent_per_tile_sweep_through_the_signed_factorisation(monkeypatch,
         assert np.array_equal(out["0"][k], out["2"][k]), k
 
 
+def test_sole_handle_rule_sees_handles_of_the_other_library_copy():
+    """the product library and the hooks build can live in one process, each with its own statics; the per-device count of live
+    handles is therefore process-wide (api.hip, live_registry).  A handle of the hooks build alive next to a product handle: neither takes
+    the persistent launch; once it is gone the product handle does again."""
+    N = 128
+    sc = Scenario(N, seed=4)
+    fr = list(sc.frames(4))
+    a = TightlyCoupledEKF(max_features=N)
+    h = TightlyCoupledEKF(max_features=N, hooks=True)
+    a.addNewFeatures(sc.initial_features()), h.addNewFeatures(sc.initial_features())
+    for z, R, p in fr[:2]:
+        for g in (a, h):
+            g.process(sc.dt)
+            assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+    assert a.persistent_sweeps() == 0 and h.persistent_sweeps() == 0
+    h.close()
+    for z, R, p in fr[2:]:
+        a.process(sc.dt)
+        assert a.updateWithFeaturePositions(z, R, p) == capi.OK
+    assert a.persistent_sweeps() == 2
+    a.close()
+
+
 def test_persistent_sweep_is_for_a_devices_sole_handle():
     """Two persistent launches in flight together could each hold part of the compute units and wait for workgroups the other
     keeps out, so the single-launch sweep is used only while a handle is alone on its device; with a second handle alive
