@@ -1171,7 +1171,7 @@ static bool gain_in_sweep_shape(const ekfvio_filter* f, int m_pad, int n_pad) {
 // must be an owner per tile pair once enough of the first owners have LEFT for every workgroup of the launch to find a compute unit (the two
 // step-0 gatherers and the gain workgroups beyond the state's row blocks leave at once).  Returns the number of owners that leave (PersistArgs::t2_skip),
 // -1 where the flow does not apply.  The flow is a property of the SHAPE, not of the sweep that runs: behind a per-step sweep of such a shape
-// t2_tiles_kernel forms the same T2, so a sequence's bits do not depend on what else the device runs.
+// gain2_t2_tiles_kernel forms the same T2, so a sequence's bits do not depend on what else the device runs.
 static int t2_skip_owners(const ekfvio_filter* f, int m_pad, int n_pad) {
     if (!f->t2_flow || !f->persist_gain || f->schur || !gain_in_sweep_shape(f, m_pad, n_pad)) return -1;
     const int mb = m_pad / PB, nX = n_pad / PB;
@@ -1385,29 +1385,27 @@ __global__ __launch_bounds__(256) void joseph_g_kernel(float* __restrict__ K, in
     if (ph == 0) Kyp[(size_t)blockIdx.y * ldg + i] = ((s_part[0][rl] + s_part[1][rl]) + s_part[2][rl]) + s_part[3][rl];
 }
 
-// T2 behind a sweep that did not form it itself (t2_tiles_kernel): Sigma = f->P in, T2 -> f->P2
-void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad) {
-    ProfScope ps(f, PC_SOLVE, (double)n_pad * n_pad * m_pad);
-    PersistArgs pa = PersistArgs();
-    pa.L = f->Laug, pa.ldl = f->ld_aug;
-    pa.mb = m_pad / PB, pa.idb0 = m_pad / PB + n_pad / PB;
-    pa.Lsign = f->Lsign;
-    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = t2_buffer(f), pa.ldt = f->ldp, pa.nstate = f->n;
-    const int nX = n_pad / PB;
-    hipLaunchKernelGGL(t2_tiles_kernel, dim3(nX * (nX + 1) / 2), dim3(256), 0, f->stream, pa);
-}
-
-// The gain, G' and K y's partial sums behind a sweep that did not form them itself (gain2_tiles_kernel; T2 flow)
+// The gain, G', K y's partial sums AND T2 behind a sweep that did not form them itself (gain2_t2_tiles_kernel; T2 flow)
 void launch_gain2_tiles(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device) {
-    ProfScope ps(f, PC_SOLVE, 2.0 * n_pad * (double)m_pad * m_pad);
+    // (with T2's tile pairs in the same launch: gain2_t2_tiles_kernel)
+    ProfScope ps(f, PC_SOLVE, 2.0 * n_pad * (double)m_pad * m_pad + (double)n_pad * n_pad * m_pad);
     PersistArgs pa = PersistArgs();
     pa.L = f->Laug, pa.ldl = f->ld_aug;
     pa.mb = m_pad / PB, pa.idb0 = m_pad / PB + n_pad / PB;
     pa.K = f->Km, pa.ldk = f->ldp;
     pa.Lsign = f->Lsign;
+    pa.Sg = f->P, pa.ldsg = f->ldp, pa.T2 = t2_buffer(f), pa.ldt = f->ldp, pa.nstate = f->n;
     GatherArgs ga = make_gather_args(f, m, m_pad, n_pad);
     if (m_on_device) ga.m_dev = f->info + 2;
-    hipLaunchKernelGGL(gain2_tiles_kernel, dim3((n_pad / PB) * pa.mb), dim3(256), 0, f->stream, pa, ga);
+    const int nX = n_pad / PB, gain_wgs = nX * pa.mb;
+    const int total = gain_wgs + nX * (nX + 1) / 2;
+    // (> 80 KB of LDS with the 53 KB of tiles: one workgroup per compute unit while the launch fits the compute units)
+    const int dyn = total <= f->num_cus ? 30 * 1024 : 0;
+    if (dyn && !f->gain2_attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gain2_t2_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 30 * 1024);
+        f->gain2_attr_set = true;
+    }
+    hipLaunchKernelGGL(gain2_t2_tiles_kernel, dim3(total), dim3(256), dyn, f->stream, pa, ga, gain_wgs);
 }
 
 void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, const float* T) {

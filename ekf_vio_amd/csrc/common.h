@@ -135,6 +135,7 @@ struct ekfvio_filter {
                                       // previous update, or by gather_potrf_kernel in front); otherwise the launcher enqueues a memset
     int fuse_sweep = 1;               // 1: gather + first diagonal tile + sweep in ONE launch where the persistent sweep applies (EKFVIO_FUSE_SWEEP)
     bool persist_attr_set = false;
+    bool gain2_attr_set = false;
     int persist_oversub = 0;          // > 0 (EKFVIO_PERSIST_OVERSUB): owner workgroups allowed per compute unit's worth of the persistent launch (chol.hip, persist_shape)
     int persist_gain = 1;             // 1 (EKFVIO_PERSIST_GAIN=0 turns it off): the gain's tiles are formed inside the fused persistent launch (chol_persist.inc)
     bool gain_in_sweep = false;       // the launch enqueued last did (launch_update then skips the gain kernel)
@@ -144,7 +145,7 @@ struct ekfvio_filter {
     int t2_flow = 1;           // 1 (EKFVIO_T2=0 turns it off): where the fused persistent launch forms the gain, freed owners also form T2 = Sigma (I - K H)^T
                                // (chol_persist.inc, t2_tile): Sigma' = T2 + K G'^T is the ONE P-update GEMM behind the launch (round 6)
     long long t2_updates = 0;  // updates enqueued (or captured) with the T2 flow: ONE P-update GEMM behind the sweep (ekfvio_get_counters [5])
-    bool t2_in_sweep = false;  // the sweep enqueued last formed T2 itself (launch_update then skips t2_tiles_kernel)
+    bool t2_in_sweep = false;  // the sweep enqueued last formed T2 itself (launch_update then skips gain2_t2_tiles_kernel)
     int schur = 0;             // 1 (EKFVIO_SCHUR=1): T2 and K as Schur tiles of the sweep; 0: gain GEMM + first Joseph GEMM behind it.
                                // Measured equal in step time at N = 256, so the simpler flow is the default.
     int fuse_linearize = 1;    // 1: structured process(dt) is one launch, the Jacobian blocks are formed inside it (EKFVIO_FUSE_LINEARIZE)
@@ -334,8 +335,7 @@ void launch_persist_fused(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_
 int live_handles_on(int device);  // api.hip: handles alive on that device in this process
 // K pruned, G = K R - T[:, idx], K y partial sums (one row of f->Wt per 64 measurement columns)
 void launch_joseph_g(ekfvio_filter* f, int m, int m_pad, int n_pad, bool m_on_device, const float* T = nullptr);  // T: the covariance G' is taken from (null: f->P)
-bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad);  // chol.hip: T2 = Sigma (I - K H)^T comes out of the sweep (or t2_tiles_kernel), ONE Joseph GEMM behind it
-void launch_t2_tiles(ekfvio_filter* f, int m_pad, int n_pad);
+bool t2_flow_shape(const ekfvio_filter* f, int m_pad, int n_pad);  // chol.hip: T2 = Sigma (I - K H)^T comes out of the sweep (or gain2_t2_tiles_kernel), ONE Joseph GEMM behind it
 // Where T2 lives between the sweep and the one GEMM behind it: the dense-F buffer, dead during an update in either predict mode (the dense
 // mode rebuilds F at the next process(dt)).  Not f->P2: that is process(dt)'s next output, and with T2 written there by other XCDs moments
 // earlier process(dt) measured 0.6 us longer (same-box rocprofv3: 9.51 against 8.90 us).

@@ -1036,14 +1036,11 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
         e1.abort = e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: both GEMMs write nothing
         if (t2_flow_shape(f, m_pad, n_pad)) {
             // Round 6: T2 = Sigma - Y S Y^T = Sigma (I - K H)^T came out of the persistent launch itself (freed owners, chol_persist.inc t2_tile; behind
-            // any other sweep of such a shape t2_tiles_kernel forms the same T2 from the stored panel blocks), in f->P2; the gain tiles of the same
-            // launch (gain_tile2; gain2_tiles_kernel otherwise) left K, G' = K R^T - (H T2)^T and the partial sums of K y.  The left Joseph factor is the ONE P-update GEMM:
+            // any other sweep of such a shape gain2_t2_tiles_kernel forms the same T2 from the stored panel blocks), in the dense-F buffer; the gain
+            // tiles of the same launch left K, G' = K R^T - (H T2)^T and the partial sums of K y.  The left Joseph factor is the ONE P-update GEMM:
             // Sigma' = (I - K H) T2 + K R K^T = T2 + K G'^T (:594-596), pruned (:625), into f->P; its extra workgroup finishes the mean (:600-609).
             f->t2_updates++;
-            if (!f->t2_in_sweep) {
-                launch_gain2_tiles(f, m, m_pad, n_pad, m_on_device);
-                launch_t2_tiles(f, m_pad, n_pad);
-            }
+            if (!f->t2_in_sweep) launch_gain2_tiles(f, m, m_pad, n_pad, m_on_device);  // (K, G', K y and T2 in one launch behind the per-step sweep)
             if (f->between_joseph) {  // (ekfvio_step_image: the frame's outputs, from mu and the partial sums of K y, in front of the one GEMM)
                 f->hook_kyp_blocks = m_pad / 64;
                 f->between_joseph(f);
