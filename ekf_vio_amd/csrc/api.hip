@@ -260,6 +260,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->persist_early = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_GEMM_ORDER2D");  // tuning knob: 0 = the throughput-regime GEMM's tiles in block-index order (rounds 1-4)
         if (e) f->gemm_order2d = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_SYM_JOSEPH");  // 0 = the throughput regime's second Joseph GEMM forms both triangles (rounds 1-5)
+        if (e) f->sym_joseph = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches
         if (e) f->fuse_linearize = atoi(e) ? 1 : 0;
     }

@@ -106,6 +106,7 @@ struct ekfvio_filter {
     int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it pays and
                                // applies (3 .. 15 block columns, grid co-resident; two block columns: 43.5 against 43.0 us per step); 0 (EKFVIO_SWEEP=0): one launch per block step
     size_t sweep_sync_words = 0;
+    int sym_joseph = 1;           // EKFVIO_SYM_JOSEPH=0: the second Joseph GEMM of the throughput regime forms both triangles (rounds 1-5)
     int gemm_order2d = 1;         // EKFVIO_GEMM_ORDER2D=0: the 64 x 64 GEMM's tiles in block-index order (rounds 1-4)
     long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
     long long schur_sweeps = 0;       // sweeps enqueued with Sigma and the gain as Schur tiles (EKFVIO_SCHUR=1): ekfvio_test_sweep_counts
@@ -255,6 +256,7 @@ struct GemmEpi {
     int* zero_words = nullptr;    // modes 2-3: the persistent sweep's flags, zeroed by workgroup (0,0) for the NEXT update's sweep
     int n_zero = 0;               // (everything but the abort word, which only ever goes up and retires the persistent path)
     int order2d = 0;              // gemm_f32_mfma_kernel: each XCD's run of tiles is a compact 2-D patch (launch_gemm_cfg decides)
+    int sym = 0;                  // mode 2, gemm_f32_mfma_kernel: only the lower triangle's tiles are formed, each also writes its transpose
     const int* abort = nullptr;   // modes 1-3: abort word of the persistent sweep in front (non-zero: the factor is unfinished) --
                                   // the kernel then writes nothing: Sigma, mu and the frame counter stay as process(dt) left them
 };

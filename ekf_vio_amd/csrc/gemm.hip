@@ -73,7 +73,20 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     // ceil(T / 8) tiles of an order that walks strips of ceil(tiles_n / 8) tile columns row by row, so the ~96 tiles an XCD has in flight share
     // ~14 row panels and ~7 column panels.  A permutation of which workgroup forms which tile: the same bits.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (epi.order2d) {
+    if (EPI == 2 && epi.sym) {
+        // Round 6, the symmetric second Joseph GEMM: Sigma' = T + G K^T is a congruence of Sigma plus K R K^T whatever K is (:594-596), symmetric
+        // up to the rounding of the two products, so only the tiles (bx >= by) of the LOWER triangle are formed -- a 1-D grid over them -- and
+        // each writes its transpose as well (epilogue).  XCD x takes the x-th contiguous run of the row-by-row tile order: a run shares its
+        // row panels of G.
+        const int T = gridDim.x, L = (int)blockIdx.x;
+        const int bq = T >> 3, br = T & 7, xcd = L & 7;
+        const int t = xcd * bq + min(xcd, br) + (L >> 3);
+        int ii = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+        while (ii * (ii + 1) / 2 > t) ii--;
+        bx = ii;
+        by = t - ii * (ii + 1) / 2;
+    } else if (epi.order2d) {
         const int tm = gridDim.x, tn = gridDim.y, T = tm * tn;
         const int L = (int)blockIdx.x + (int)blockIdx.y * tm;
         const int bq = T >> 3, br = T & 7, xcd = L & 7;
@@ -359,6 +372,23 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
         for (int r = 0; r < 16; r++) {
             const int jo = (r & 3) + 8 * (r >> 2);
             if (j0 + wc * 32 + 4 * lk + jo < N) cp[(size_t)jo * ldc] = vout[r];
+        }
+    }
+    if (EPI == 2 && epi.sym && bx != by) {
+        // the mirror tile Sigma'(j0.., i0..) = this tile's transpose, turned through LDS (B's staging buffers, 64 x 65 floats, free since the K
+        // loop) so that it is written along ITS contiguous dimension.  (In place: nobody reads the upper tiles of T in this launch.)
+        static_assert(!TRANSB || 2 * BK * LDS_BN >= 64 * 65, "turning tile");
+        float* tr = &BsG[0][0][0];
+        __syncthreads();
+        const int il = wr * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; r++) tr[il * 65 + wc * 32 + 4 * lk + (r & 3) + 8 * (r >> 2)] = vout[r];
+        __syncthreads();
+        const int jm = j0 + il;  // this lane's row of the mirror tile
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int io = wc * 32 + 4 * lk + (r & 3) + 8 * (r >> 2);  // its column i0 + io
+            if (jm < N && i0 + io < M) C[(size_t)(i0 + io) * ldc + jm] = tr[io * 65 + il];
         }
     }
     GSTAMP(38);
@@ -793,9 +823,11 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
     }
     const int groups = cfg == 2 ? 2 : 1;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    e.sym = (e.sym && e.mode == 2 && M == N && transB) ? 1 : 0;
+    if (e.sym) grid = dim3(grid.x * (grid.x + 1) / 2);  // the lower triangle's tiles
     // throughput regime (several tiles per compute unit and a full contraction per tile): compact 2-D patches per XCD.  Not for the
     // triangular-aware gain GEMM: its tiles' work falls with the tile column, and strips of columns would load the XCDs unevenly.
-    e.order2d = (f->gemm_order2d && !lowerB && (int)(grid.x * grid.y) >= 2 * cus) ? 1 : 0;
+    e.order2d = (!e.sym && f->gemm_order2d && !lowerB && (int)(grid.x * grid.y) >= 2 * cus) ? 1 : 0;
 #define GEMM_GO(TB, G, EP)                                                                                             \
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<TB, G, EP>), grid, dim3(256 * G), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, \
                        Cin, ldcin, C, ldc, flush, lowerB, e)

@@ -141,7 +141,9 @@ def test_teacher_forced_one_step_n1024(oracle_threads):
     pp[[5, 77, 500, 1023]] = 0  # m = 2040, m_pad = 2048
     E, _ = _teacher_forced(g, o32, o64, st32, sc.dt, zz, RR, pp)
     _assert_within_yardstick(E)
-    assert E["sig_pair"] < 1e-4, E
+    # (the two fp32 evaluations differ in rounding order and, since round 6, in the upper triangle being the lower one's mirror on the HIP side:
+    # 0.99e-4 with both triangles formed, 1.01e-4 mirrored -- scripts/sym_joseph_check.py)
+    assert E["sig_pair"] < 1.5e-4, E
     g.close()
 
 
@@ -393,3 +395,65 @@ def test_t2_flow_leaves_the_covariance_as_definite_as_the_two_gemm_flow(monkeypa
         g.close()
     for a, b, floor in zip(err["t2"], err["gemm"], (2e-6, 2e-6, 2e-6)):
         assert a <= 1.5 * b + floor, err
+
+
+def test_symmetric_second_joseph_gemm_is_the_full_one_mirrored(monkeypatch, oracle_threads):
+    """Round 6.  In the throughput regime (more 64 x 64 tiles than compute units: N > 334 all measured) the second Joseph GEMM,
+    Sigma' = T + G K^T (TightlyCoupledEKF.cpp:594-596), forms only the tiles of the lower triangle and writes each one's transpose as well
+    (gemm.hip, GemmEpi::sym): the update is a congruence with ONE gain, symmetric in exact arithmetic whatever the gain is.
+    Pinned against the both-triangles launch (EKFVIO_SYM_JOSEPH=0, rounds 1-5) from the same state:
+      * the lower triangle and the mean have the SAME BITS (the same products in the same order); the upper triangle is the lower one's mirror
+        outside the diagonal tiles;
+      * what is dropped is the reference arithmetic's own upper triangle, which differs from the mirror by the ANTISYMMETRIC part of the result --
+        fp32 rounding noise of the filter's history that the congruence carries along (2e-4 of the norm after three updates at N = 1024:
+        profiles/r06_sym_joseph.txt), not information.  Stated as a tolerance, teacher-forced from a state that CARRIES such noise (made by
+        the both-triangles flow): on the lower triangle the 4x yardstick of this file against the fp64 evaluation; on the upper triangle at most
+        that plus the fp64 result's own antisymmetric part."""
+    N = 512
+    sc = Scenario(N, seed=3)
+    frames = list(sc.frames(4))
+    monkeypatch.setenv("EKFVIO_SYM_JOSEPH", "0")
+    g = TightlyCoupledEKF(max_features=N)
+    g.addNewFeatures(sc.initial_features())
+    st = g.get_state()
+    d = np.diag(st["Sigma"]).copy()
+    d[7:16] = 0.05
+    d[24::3] = 1.0
+    st["Sigma"] = np.diag(d).astype(np.float32)
+    st["base_mu"][7:10] = (-0.1, 0.0, -0.1)
+    st["base_mu"][10:13] = (0.0, 0.1, 0.0)
+    g.set_state(st)
+    for z, R, p in frames[:3]:
+        g.process(sc.dt)
+        assert g.updateWithFeaturePositions(z, R, p) == capi.OK
+    st32 = g.get_state()
+    g.close()
+    S0 = st32["Sigma"].astype(np.float64)
+    assert np.linalg.norm(S0 - S0.T) > 1e-6 * np.linalg.norm(S0)  # the start does carry antisymmetric noise
+    z, R, p = frames[3]
+    out = {}
+    for sym in ("0", "1"):
+        monkeypatch.setenv("EKFVIO_SYM_JOSEPH", sym)
+        g = TightlyCoupledEKF(max_features=N)
+        o32, o64 = OracleFilter(np.float32), OracleFilter(np.float64)
+        E, s64 = _teacher_forced(g, o32, o64, st32, sc.dt, z, R, p)
+        sg = g.get_state()
+        out[sym] = (sg["Sigma"].copy(), sg["base_mu"].copy(), sg["feat_mu"].copy(), E, s64["Sigma"].astype(np.float64),
+                    o32.get_state()["Sigma"].astype(np.float64), g.checkSigma()[1])
+        g.close(), o32.close(), o64.close()
+    full, half = out["0"], out["1"]
+    _assert_within_yardstick(full[3])
+    n = full[0].shape[0]
+    lower = np.tril(np.ones((n, n), dtype=bool))
+    assert np.array_equal(full[0][lower], half[0][lower])
+    assert np.array_equal(full[1], half[1]) and np.array_equal(full[2], half[2])
+    blk = np.arange(n) // 64
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal(half[0][off], half[0].T[off])
+    assert not np.array_equal(full[0][off], full[0].T[off])  # (the full launch's two triangles do differ)
+    assert half[6] <= full[6]  # checkSigma's asymmetry number: what is left sits in the diagonal tiles
+    S, S64, S32 = half[0].astype(np.float64), half[4], half[5]
+    nrm = lambda M, msk: float(np.linalg.norm(M[msk]))  # noqa: E731
+    assert nrm(S - S64, lower) <= ACC_FACTOR * nrm(S32 - S64, lower) + SIG_FLOOR * nrm(S64, lower)
+    upper = ~lower
+    assert nrm(S - S64, upper) <= nrm(S64 - S64.T, upper) + ACC_FACTOR * nrm(S32 - S64, lower) + SIG_FLOOR * nrm(S64, upper)
