@@ -21,6 +21,7 @@ t0 = v[0]
 if v[1] and v[3]:  # fused launch (round 4): the chain workgroup's own prologue
     print("fused launch, chain workgroup: tile (0,0) gather %d  factorisation %d  stores + ready[0] + wait for the gather workgroups %d  (step 0 starts %d cycles after the launch's first stamp)"
           % (v[1] - v[0], v[2] - v[1], v[3] - v[2], v[32] - v[0]))
+    print("tile (0,0): the one-batch guess (all of the first 32 landmarks measured) %s" % ("held" if v[900] else "did NOT hold: gathered again"))
 for k in range(mb - 1):
     b = 32 + 8 * k
     e = [v[b + i] for i in range(6)] + [v[b + 8]]
