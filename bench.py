@@ -347,17 +347,19 @@ def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="struc
         n, m_pad = 22 + 3 * n_landmarks, ((2 * n_landmarks + 63) // 64) * 64
         avg_us, flops_per_launch = g.profile_update_gemms(20)
         tf = flops_per_launch / (avg_us * 1e-6) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "P-update GEMM pair (Sigma - K W, T + G K^T): gemm_f32_mfma_kernel, 64 x 64 tiles, three workgroups per compute unit",
+        out["roofline"] = {"bound": "mfma", "kernel": "P-update GEMM pair (Sigma - K W: all tiles; T + G K^T: the lower triangle's tiles, mirrored -- round 6): gemm_f32_mfma_kernel, 64 x 64 tiles, three workgroups per compute unit; flops_per_launch = EXECUTED flops, averaged over the pair",
                            "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
                            "flops_per_launch": flops_per_launch, "avg_launch_us": avg_us, "shape": {"M": n, "N": n, "K": m_pad},
                            "traffic": None, "algorithmic_bytes_per_launch": 4.0 * (2.0 * n * m_pad + 2.0 * n * n),
-                           "note": "pairs replayed back to back from a graph on the filter's own operands; rocprofv3 means of the same launches inside the step: profiles/r05_kernel_stats_n1024.csv"}
-        for tag in ("r05",):
+                           "note": "pairs replayed back to back from a graph on the filter's own operands; rocprofv3 means of the same launches inside the step: profiles/r06_kernel_stats_n1024.csv"}
+        for tag in ("r05", "r06"):  # (the newest record wins)
             pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_n1024.json" % tag)
             if n_landmarks == 1024 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 if "p_update_gemm_traffic_bytes_per_launch" in pj:
                     out["roofline"]["traffic"] = pj["p_update_gemm_traffic_bytes_per_launch"]
+                    if "p_update_gemm_algorithmic_bytes_per_launch" in pj:
+                        out["roofline"]["algorithmic_bytes_per_launch"] = pj["p_update_gemm_algorithmic_bytes_per_launch"]
                     out["roofline"]["traffic_quoted_from_profiles"] = True
                     out["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic_n1024.json" % tag
         g.profile(True)
@@ -367,6 +369,11 @@ def device_resident_rate(n_landmarks, device, steps=200, warm=20, predict="struc
         g.profile(False)
         out["stage_us_per_step"] = {k: 1e3 * v["ms"] / 6 for k, v in rep.items() if v["launches"]}
         fl = step_flops(n_landmarks)
+        if not g.counters()["t2_updates"] and os.environ.get("EKFVIO_SYM_JOSEPH", "1") != "0" and (n + 63) // 64 * ((n + 63) // 64) > 256:
+            tn = (n + 63) // 64  # executed, not dense-form, flops: the second Joseph GEMM forms tn (tn + 1) / 2 of its tn^2 tiles
+            cut = 2.0 * n * n * m_pad - 0.5 * tn * (tn + 1) * 2.0 * 64 * 64 * m_pad
+            fl["joseph_gemms"] -= cut
+            fl["total"] -= cut
         out["roofline_step"] = {"flops_per_step": fl["total"], "achieved": fl["total"] / (out["ms_per_step"] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                                 "unit": "TFLOP/s", "frac": fl["total"] / (out["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     if predict == "dense":

@@ -903,7 +903,15 @@ int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_laun
     HIPC(f, hipStreamSynchronize(f->stream));
     *avg_launch_us = 1e3 * ms / ((double)per_rep * reps);
     const int m_pad = round_up(f->last_m, 64);
-    if (flops_per_launch) *flops_per_launch = 2.0 * f->n * (double)f->n * m_pad;
+    if (flops_per_launch) {
+        // EXECUTED flops, averaged over the launches of one update: the second Joseph GEMM of the throughput regime forms the lower triangle's
+        // 64 x 64 tiles only (GemmEpi::sym)
+        const double full = 2.0 * f->n * (double)f->n * m_pad;
+        const int tn = (f->n + 63) / 64;
+        const bool half = per_rep == 2 && f->sym_joseph && gemm_throughput_regime(f, f->n, f->n, m_pad);
+        const double second = half ? 0.5 * tn * (tn + 1) * 2.0 * 64.0 * 64.0 * m_pad : full;
+        *flops_per_launch = per_rep == 2 ? 0.5 * (full + second) : full;
+    }
     return EKFVIO_OK;
 }
 int ekfvio_profile_reset(ekfvio_filter* f) {

@@ -264,6 +264,8 @@ void launch_gemm(ekfvio_filter* f, int transB, int M, int N, int K, float alpha,
                  int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush, int lowerB = 0,
                  const GemmEpi* epi = nullptr);
 
+bool gemm_throughput_regime(const ekfvio_filter* f, int M, int N, int K);
+
 // same, selecting a tile configuration (0 = production default chosen by shape)
 void launch_gemm_variant(ekfvio_filter* f, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, const float* Cin, int ldcin, float* C, int ldc, int flush,

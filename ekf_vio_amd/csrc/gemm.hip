@@ -773,6 +773,12 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     GSTAMP(38);
 }
 
+// true where launch_gemm forms A * B^T with the 64 x 64 kernel (more 64-row tiles than compute units): the regime in which GemmEpi::sym is heeded
+bool gemm_throughput_regime(const ekfvio_filter* f, int M, int N, int K) {
+    const int cus = f->num_cus > 0 ? f->num_cus : 256;
+    return !(K % 64 == 0 && ((M + 63) / 64) * ((N + 63) / 64) <= cus);
+}
+
 // cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
 // (512 threads); +100 = the same with 256 threads
 static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -249,7 +249,8 @@ EKFVIO_API int ekfvio_profile_get(ekfvio_filter* f, int32_t cls, double* total_m
 /* Mean launch duration (us) of the P-update GEMM(s) at the shape of the most recent update -- Sigma' = T + G K^T, and,
  * where the sweep does not produce T itself (EKFVIO_SCHUR=0, m >= 1024), T = Sigma - K W as well -- `reps` repetitions
  * replayed back to back from one hipGraph between two HIP events on the handle's stream; results go to scratch, the
- * state is untouched.  flops_per_launch = 2 n n m_pad (may be NULL). */
+ * state is untouched.  flops_per_launch (may be NULL) = the flops a launch EXECUTES, averaged over the update's P-update
+ * launches: 2 n n m_pad, less where the second Joseph GEMM forms the lower triangle's tiles only (N > 334, round 6). */
 EKFVIO_API int ekfvio_profile_update_gemms(ekfvio_filter* f, int32_t reps, double* avg_launch_us, double* flops_per_launch);
 
 /* Diagnostic counters of a handle (no device work): counters[0] Cholesky sweeps that went out as the single persistent launch

@@ -18,3 +18,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_n1024 -o ekfvio -- python3 $ROOT/bench.py --steps 40 --warmup 10 --landmarks 1024 --no-cpu-baseline --no-full-loop --replay-only > $OUT/rocprof_${TAG}_n1024.log 2>&1; echo "rocprof n1024 rc=$?"
 cd $ROOT
 bash scripts/gpu_pmc.sh $TAG && bash scripts/gpu_pmc_mfma.sh $TAG
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_n1024_$c -o p -- python3 $ROOT/bench.py --landmarks 1024 --steps 12 --warmup 3 --no-cpu-baseline --no-full-loop > $OUT/pmc_${TAG}_n1024_$c.log 2>&1
+  echo "pmc n1024 $c rc=$?"
+done
+cd $ROOT
