@@ -507,22 +507,6 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         const int tI = blockIdx.x / tiles_side, tJ = blockIdx.x % tiles_side;
         const int f0 = tI * PT, g0 = tJ * PT;
         if (tid < 81) sPbb[tid] = P[(size_t)(7 + tid % 9) * ld + 7 + tid / 9];
-        // This thread's own 3x3 block of Sigma is requested FIRST: it is not needed before the third barrier, and the
-        // staging, the derivative columns and X on the base columns all run while it flies (round 6: the tile used to
-        // ask for it after that barrier, so a workgroup had bytes in flight for a third of its life).
-        const int lf = tid % PT, lg = tid / PT;
-        const int of = f0 + lf, og = g0 + lg;
-        const bool own = of < N && og < N;
-        float Pfg[3][3];  // own block P(22+3f+q, 22+3g+s)
-        if (own) {
-#pragma unroll
-            for (int sIdx = 0; sIdx < 3; sIdx++) {
-                const float3 c3 = *reinterpret_cast<const float3*>(P + (size_t)(EKF_BASE + 3 * og + sIdx) * ld + EKF_BASE + 3 * of);
-                Pfg[0][sIdx] = c3.x;
-                Pfg[1][sIdx] = c3.y;
-                Pfg[2][sIdx] = c3.z;
-            }
-        }
         // LIN: the two derivative columns this thread forms: task = side*192 + landmark*12 + column, tasks tid and
         // tid + 256 (< 384); on the diagonal tiles threads 128..143 propagate the landmarks' means in their second slot
         float lu[2] = {0.f, 0.f}, lv[2] = {0.f, 0.f}, lrho[2] = {1.f, 1.f};
@@ -633,8 +617,19 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
         // Lanes run along f, the ROW landmark: the 16 lanes of a group read / write 48 contiguous floats of a column of Sigma (three
         // floats each, one 12-byte access), four columns groups per wavefront.  (Rounds 1-4 had the lanes along g: sixteen
         // columns per access, 12 bytes apart in each -- 1.8 TB/s of the 8 n^2 bytes at N = 1024, where Sigma is 38 MB.)
-        if (!own) return;
-        const int f = of, g = og;
+        // (Requesting this block in front of the staging instead -- it is not needed before here -- was tried in round 6 and is SLOWER, 9.0 -> 9.3 us
+        // at N = 256 and 30 -> 35.5 us at N = 1024: vmcnt retires in order, so the staged operands' first barrier then waits for these loads too.)
+        const int lf = tid % PT, lg = tid / PT;
+        const int f = f0 + lf, g = g0 + lg;
+        if (f >= N || g >= N) return;
+        float Pfg[3][3];  // own block P(22+3f+q, 22+3g+s)
+#pragma unroll
+        for (int sIdx = 0; sIdx < 3; sIdx++) {
+            const float3 c3 = *reinterpret_cast<const float3*>(P + (size_t)(EKF_BASE + 3 * g + sIdx) * ld + EKF_BASE + 3 * f);
+            Pfg[0][sIdx] = c3.x;
+            Pfg[1][sIdx] = c3.y;
+            Pfg[2][sIdx] = c3.z;
+        }
         float Xg[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++)
