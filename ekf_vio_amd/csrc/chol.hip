@@ -1295,11 +1295,8 @@ void launch_chol_sweep(ekfvio_filter* f, float* Saug, float* Laug, float* Linv, 
         la.mb = mb, la.rb = rb, la.idb0 = idb0, la.info = f->info, la.Lsign = f->Lsign;
         {
             for (int l = 0; l + 1 < mb; l++) {
-                const int r = mb - 1 - l;
-                int far = 0;  // columns l+2, l+4, ... from the diagonal down plus the extra rows
-                if (l >= 1)
-                    for (int j = l + 2; j < mb; j += 2) far += mb - j + rb;
-                hipLaunchKernelGGL(chol_step_la_kernel, dim3(r + rb + far), dim3(256), 0, f->stream, la, l);
+                const int grid = la_near_tasks(mb, idb0, rb, l) + la_far_tasks(mb, idb0, rb, l);  // (chol_step_la.inc)
+                hipLaunchKernelGGL(chol_step_la_kernel, dim3(grid), dim3(256), 0, f->stream, la, l);
             }
         }
         hipLaunchKernelGGL(chol_panel_kernel, dim3(rb), dim3(256), 0, f->stream, Saug, ld, Laug, ld, Linv, mb - 1, mb, 0, idb0, f->Lsign, 0);
