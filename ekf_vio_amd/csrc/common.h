@@ -256,6 +256,7 @@ struct GemmEpi {
     int* zero_words = nullptr;    // modes 2-3: the persistent sweep's flags, zeroed by workgroup (0,0) for the NEXT update's sweep
     int n_zero = 0;               // (everything but the abort word, which only ever goes up and retires the persistent path)
     int order2d = 0;              // gemm_f32_mfma_kernel: each XCD's run of tiles is a compact 2-D patch (launch_gemm_cfg decides)
+    int sym_w = 1;                // ... in strips of sym_w tile columns, each walked row by row
     int sym = 0;                  // mode 2, gemm_f32_mfma_kernel: only the lower triangle's tiles are formed, each also writes its transpose
     const int* abort = nullptr;   // modes 1-3: abort word of the persistent sweep in front (non-zero: the factor is unfinished) --
                                   // the kernel then writes nothing: Sigma, mu and the frame counter stay as process(dt) left them

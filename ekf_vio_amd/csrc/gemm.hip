@@ -76,16 +76,35 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
     if (EPI == 2 && epi.sym) {
         // Round 6, the symmetric second Joseph GEMM: Sigma' = T + G K^T is a congruence of Sigma plus K R K^T whatever K is (:594-596), symmetric
         // up to the rounding of the two products, so only the tiles (bx >= by) of the LOWER triangle are formed -- a 1-D grid over them -- and
-        // each writes its transpose as well (epilogue).  XCD x takes the x-th contiguous run of the row-by-row tile order: a run shares its
-        // row panels of G.
+        // each writes its transpose as well (epilogue).  XCD x takes the x-th contiguous run of the tile order below.
         const int T = gridDim.x, L = (int)blockIdx.x;
         const int bq = T >> 3, br = T & 7, xcd = L & 7;
-        const int t = xcd * bq + min(xcd, br) + (L >> 3);
-        int ii = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-        while (ii * (ii + 1) / 2 > t) ii--;
-        bx = ii;
-        by = t - ii * (ii + 1) / 2;
+        int t = xcd * bq + min(xcd, br) + (L >> 3);
+        // the order: strips of sym_w tile columns, each walked row by row from its diagonal down (row c0 + r of a strip has min(r + 1, w) tiles)
+        const int tn = (N + BN - 1) / BN;
+        int c0 = 0, w = 1;
+        for (;;) {
+            w = min(epi.sym_w, tn - c0);
+            const int cnt = w * (w - 1) / 2 + w * (tn - c0 - (w - 1));
+            if (t < cnt || c0 + w >= tn) break;
+            t -= cnt;
+            c0 += w;
+        }
+        const int head = w * (w - 1) / 2;
+        if (t < head) {
+            int r = 0;
+            while (t >= r + 1) {
+                t -= r + 1;
+                r++;
+            }
+            bx = c0 + r;
+            by = c0 + t;
+        } else {
+            t -= head;
+            const int r = t / w;
+            bx = c0 + (w - 1) + r;
+            by = c0 + (t - r * w);
+        }
     } else if (epi.order2d) {
         const int tm = gridDim.x, tn = gridDim.y, T = tm * tn;
         const int L = (int)blockIdx.x + (int)blockIdx.y * tm;
@@ -830,7 +849,12 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
     const int groups = cfg == 2 ? 2 : 1;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
     e.sym = (e.sym && e.mode == 2 && M == N && transB) ? 1 : 0;
-    if (e.sym) grid = dim3(grid.x * (grid.x + 1) / 2);  // the lower triangle's tiles
+    if (e.sym) {
+        // strips of ceil(tn / 8) tile columns, as order2d's: measured at tn = 49 (FETCH_SIZE x 2 per launch, scripts/sym_w_sweep.sh) row by row 572 MB,
+        // strips of 12 / 7 / 4 / 3 columns 296 / 258 / 277 / 312 MB, the launch's duration the same within 0.5 % (it is MFMA-bound)
+        e.sym_w = ((int)grid.x + 7) >> 3;
+        grid = dim3(grid.x * (grid.x + 1) / 2);  // the lower triangle's tiles
+    }
     // throughput regime (several tiles per compute unit and a full contraction per tile): compact 2-D patches per XCD.  Not for the
     // triangular-aware gain GEMM: its tiles' work falls with the tile column, and strips of columns would load the XCDs unevenly.
     e.order2d = (!e.sym && f->gemm_order2d && !lowerB && (int)(grid.x * grid.y) >= 2 * cus) ? 1 : 0;
