@@ -435,7 +435,44 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_f32_mfma_kernel(int M, int 
 template <int EPI>
 __device__ __forceinline__ void gemm16_finish_mean(const GemmEpi& epi) {
     __shared__ float s_q[4];
-    for (int e = threadIdx.x; e < epi.n; e += 256) {
+    // Everything this workgroup reads is requested at once -- the abort word of the persistent sweep in front, the partial sums of K y and the mean
+    // for up to four elements per thread (n <= 1024 wherever a launch is a single wave of tiles) -- and the stores follow: written as a loop over
+    // e with the store inside, the iterations' round trips go out one behind the other (mu may alias what is loaded), after the abort word's own,
+    // and inside each the block columns' partial sums one by one: dependent round trips by the dozen made this workgroup end about when the tiles
+    // do (round 6, profiles/r06_lin_pre_experiment.txt).
+    int aborted = 0;
+    if (epi.abort) aborted = *epi.abort;  // (an aborted persistent sweep in front: this update writes nothing)
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = min((int)threadIdx.x + 256 * u, epi.n - 1);
+        if (EPI == 3) {
+            // (the partial sums of up to 16 block columns as one batch from clamped addresses, added in block order afterwards: a loop with a
+            // run-time bound is compiled load - wait - add, one round trip per block column)
+            float pk[16];
+#pragma unroll
+            for (int cb = 0; cb < 16; cb++) pk[cb] = epi.Kyp[(size_t)min(cb, epi.kyp_blocks - 1) * epi.kyp_ld + e];
+            const float m0 = epi.mu[e];
+            float ky = pk[0];
+#pragma unroll
+            for (int cb = 1; cb < 16; cb++) ky = (cb < epi.kyp_blocks) ? ky + pk[cb] : ky;
+            for (int cb = 16; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
+            v4[u] = m0 + ky;
+        } else {
+            v4[u] = epi.mu[e] + epi.Pcol[e];
+        }
+    }
+    if (aborted) return;  // (uniform)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = (int)threadIdx.x + 256 * u;
+        if (e < epi.n) {
+            if (EPI != 3) epi.Pcol[e] = 0.f;
+            if (e >= 3 && e <= 6) s_q[e - 3] = v4[u];
+            else epi.mu[e] = v4[u];
+        }
+    }
+    for (int e = threadIdx.x + 1024; e < epi.n; e += 256) {  // (not reached by the shapes this kernel is chosen for)
         float v;
         if (EPI == 3) {
             float ky = epi.Kyp[e];
@@ -445,8 +482,7 @@ __device__ __forceinline__ void gemm16_finish_mean(const GemmEpi& epi) {
             v = epi.mu[e] + epi.Pcol[e];
             epi.Pcol[e] = 0.f;
         }
-        if (e >= 3 && e <= 6) s_q[e - 3] = v;
-        else epi.mu[e] = v;
+        epi.mu[e] = v;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): s_q written
     __builtin_amdgcn_s_barrier();        // (the workgroup's other wavefronts have returned)
@@ -482,9 +518,7 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     // (EPI 2 / 3 with a mean to finish: one workgroup more than tiles)
     if ((EPI == 2 || EPI == 3) && (int)blockIdx.x == tiles_x * tiles_y) {
         if (threadIdx.x >= 256) return;
-        int aborted = 0;
-        if (epi.abort) aborted = *epi.abort;  // (an aborted persistent sweep in front: this update writes nothing)
-        if (!aborted && epi.n > 0) gemm16_finish_mean<EPI>(epi);
+        if (epi.n > 0) gemm16_finish_mean<EPI>(epi);
         return;
     }
     // XCD-aware tile order (bijective for any grid size)
