@@ -260,6 +260,8 @@ static int create_body(ekfvio_filter* f, const ekfvio_config* cfg, int device, v
         if (e) f->persist_early = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_GEMM_ORDER2D");  // tuning knob: 0 = the throughput-regime GEMM's tiles in block-index order (rounds 1-4)
         if (e) f->gemm_order2d = atoi(e) ? 1 : 0;
+        e = getenv("EKFVIO_LIN_OVERLAP");  // 0 = every process(dt) of a device-resident run linearises for itself (rounds 3-5)
+        if (e) f->lin_overlap = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_SYM_JOSEPH");  // 0 = the throughput regime's second Joseph GEMM forms both triangles (rounds 1-5)
         if (e) f->sym_joseph = atoi(e) ? 1 : 0;
         e = getenv("EKFVIO_FUSE_LINEARIZE");  // tuning knob: 0 = linearize_kernel and the propagation as two launches
@@ -765,8 +767,14 @@ static int capture_steps(ekfvio_filter* f, int steps, int m, float dt, int* coun
         // the frame's measurement bookkeeping rides in the process(dt) launch
         const BookArgs bk = make_book_args(f, m, f->seq_z, f->seq_R, f->seq_pass, counter);
         launch_predict(f, dt, &bk);
+        // round 6: inside a graph the next step's dt is known -- every update but the graph's last lets its last GEMM linearise for the step
+        // behind it (launch_update decides whether the shape allows it; the graph's last update leaves the next replay's first step to
+        // linearise for itself, so a graph needs nothing from whatever ran before it)
+        f->lin_next_dt = (k + 1 < steps) ? dt : -1.f;
         launch_update(f, m, f->seq_z, f->seq_R, f->seq_pass, counter, f->seq_frames, true);
+        f->lin_next_dt = -1.f;
     }
+    f->prelinearized = false;
     hipError_t ce = hipStreamEndCapture(f->stream, &g);
     f->graph_leaves_flags_clean = f->sweep_flags_clean;  // (the same for every step count: the last update's last GEMM decides)
     f->sweep_flags_clean = mirror;

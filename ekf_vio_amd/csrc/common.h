@@ -106,6 +106,9 @@ struct ekfvio_filter {
     int sweep_mode = 2;        // 2: ONE persistent launch with per-tile hand-offs behind the first diagonal tile (chol_persist.inc), where it pays and
                                // applies (3 .. 15 block columns, grid co-resident; two block columns: 43.5 against 43.0 us per step); 0 (EKFVIO_SWEEP=0): one launch per block step
     size_t sweep_sync_words = 0;
+    float lin_next_dt = -1.f;     // >= 0 (set by capture_steps around launch_update): the next process(dt)'s dt -- the update's last GEMM may linearise for it
+    bool prelinearized = false;   // ... and did: FA / FB / FD / mu_next hold the next step's Jacobian blocks and propagated mean (launch_predict then skips its own)
+    int lin_overlap = 1;          // EKFVIO_LIN_OVERLAP=0 turns that off (A/B)
     int sym_joseph = 1;           // EKFVIO_SYM_JOSEPH=0: the second Joseph GEMM of the throughput regime forms both triangles (rounds 1-5)
     int gemm_order2d = 1;         // EKFVIO_GEMM_ORDER2D=0: the 64 x 64 GEMM's tiles in block-index order (rounds 1-4)
     long long persistent_sweeps = 0;  // sweeps enqueued (or captured) as chol_persist_kernel: ekfvio_test_persistent_sweeps
@@ -256,6 +259,17 @@ struct GemmEpi {
     int* zero_words = nullptr;    // modes 2-3: the persistent sweep's flags, zeroed by workgroup (0,0) for the NEXT update's sweep
     int n_zero = 0;               // (everything but the abort word, which only ever goes up and retires the persistent path)
     int order2d = 0;              // gemm_f32_mfma_kernel: each XCD's run of tiles is a compact 2-D patch (launch_gemm_cfg decides)
+    // round 6 (mode 3, gemm16_kernel): the linearisation of the NEXT process(dt) in `lin_blocks` workgroups behind the tiles' and the mean's -- a device-resident run
+    // knows the next dt, and K y is final before the launch (Kyp), so numericallyLinearizeProcess (:176-325) and the mean propagation at mu + K y run while
+    // this launch's tiles do, and the covariance propagation behind it only has the strips left (motion_model.inc, launch_update)
+    int lin_blocks = 0;
+    int lin_N = 0;
+    float lin_dt = 0.f;
+    float* lin_FA = nullptr;
+    float* lin_FB = nullptr;
+    float* lin_FD = nullptr;
+    float* lin_mu_next = nullptr;
+    int mean_keep = 0;            // (set by launch_gemm_cfg with lin_blocks) gemm16_finish_mean leaves mu alone
     int sym_w = 1;                // ... in strips of sym_w tile columns, each walked row by row
     int sym = 0;                  // mode 2, gemm_f32_mfma_kernel: only the lower triangle's tiles are formed, each also writes its transpose
     const int* abort = nullptr;   // modes 1-3: abort word of the persistent sweep in front (non-zero: the factor is unfinished) --
@@ -266,6 +280,8 @@ void launch_gemm(ekfvio_filter* f, int transB, int M, int N, int K, float alpha,
                  const GemmEpi* epi = nullptr);
 
 bool gemm_throughput_regime(const ekfvio_filter* f, int M, int N, int K);
+// would launch_gemm run A * B^T of this shape as ONE wave of gemm16_kernel workgroups with `extra` more workgroups still inside that wave?
+bool gemm_single_round_with(const ekfvio_filter* f, int M, int N, int K, int extra);
 
 // same, selecting a tile configuration (0 = production default chosen by shape)
 void launch_gemm_variant(ekfvio_filter* f, int variant, int transB, int M, int N, int K, float alpha, const float* A, int lda,

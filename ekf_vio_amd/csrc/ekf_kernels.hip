@@ -16,126 +16,7 @@
 
 namespace {
 
-struct Q4 {
-    float w, x, y, z;
-};
-struct V3 {
-    float x, y, z;
-};
-
-__device__ inline V3 cross3(const V3& a, const V3& b) {
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
-}
-// Eigen QuaternionBase::_transformVector: v + w*uv + qv x uv, uv = 2 (qv x v)
-__device__ inline V3 qrot(const Q4& q, const V3& v) {
-    V3 qv{q.x, q.y, q.z};
-    V3 uv = cross3(qv, v);
-    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
-    V3 c = cross3(qv, uv);
-    return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
-}
-// The reference is an x86-64 build of Eigen with its vectorisation on (CMakeLists.txt:15 overwrites the -msse* flags of
-// :9, so plain x86-64: SSE2, no SSE3 / FMA): the three functions below follow that build's rounding order (the CPU
-// restatement used by the tests follows the same order by default and measures how far the other builds are away:
-// tests/test_oracle_variants_cpu.py).
-// Vector4f::squaredNorm() over the coefficients (x,y,z,w): a packet of squares reduced by SSE2 predux, (c0+c2)+(c1+c3)
-__device__ inline float squared_norm4(const Q4& q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
-__device__ inline Q4 qinverse(const Q4& q) {
-    float n2 = squared_norm4(q);
-    if (n2 > 0.f) return {q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
-    return {0.f, 0.f, 0.f, 0.f};
-}
-__device__ inline Q4 qnormalized(const Q4& q) {
-    float n = sqrtf(squared_norm4(q));
-    return {q.w / n, q.x / n, q.y / n, q.z / n};
-}
-// Geometry_SSE.h quat_product<Architecture::SSE, ., ., float>:
-// (a * b.wwww - a.zxyx * b.yzxx) + (+,+,+,-)(a.yzxz * b.zxyz + a.wwwy * b.xyzy)
-__device__ inline Q4 qmul(const Q4& a, const Q4& b) {
-    Q4 r;
-    r.x = (a.x * b.w - a.z * b.y) + (a.y * b.z + a.w * b.x);
-    r.y = (a.y * b.w - a.x * b.z) + (a.z * b.x + a.w * b.y);
-    r.z = (a.z * b.w - a.y * b.x) + (a.x * b.y + a.w * b.z);
-    r.w = (a.w * b.w - a.x * b.x) + (-(a.z * b.z + a.y * b.y));
-    return r;
-}
-__device__ inline float norm3(const V3& v) { return sqrtf(v.x * v.x + (v.y * v.y + v.z * v.z)); }
-
-// dt*vel + 0.5*dt*dt*accel with the 0.5*dt*dt factor evaluated in double (:338, :420)
-__device__ inline V3 translation(const V3& vel, const V3& acc, float dt) {
-    float h = (float)(0.5 * (double)dt * (double)dt);
-    return {dt * vel.x + h * acc.x, dt * vel.y + h * acc.y, dt * vel.z + h * acc.z};
-}
-// exp(omega dt) (:340-355); sign = -1 is the conjugate built by convolveFeature (:427-440)
-__device__ inline Q4 delta_quat(const V3& om, float dt, float sign) {
-    float on = norm3(om);
-    if (on < 1e-10f) {
-        Q4 q{1.f, sign * om.x * dt, sign * om.y * dt, sign * om.z * dt};
-        return qnormalized(q);
-    }
-    float theta = dt * on;
-    V3 oh{om.x / on, om.y / on, om.z / on};
-    float half = theta / 2;
-    float st2 = (float)sin((double)half);
-    float ct2 = (float)cos((double)half);
-    return {ct2, sign * oh.x * st2, sign * oh.y * st2, sign * oh.z * st2};
-}
-
-// convolveBaseState (:328-395)
-__device__ inline void convolve_base(const float* last, float dt, float* out) {
-    V3 pos{last[0], last[1], last[2]};
-    Q4 quat{last[3], last[4], last[5], last[6]};
-    V3 vel{last[7], last[8], last[9]};
-    V3 om{last[10], last[11], last[12]};
-    V3 acc{last[13], last[14], last[15]};
-    V3 d = qrot(quat, translation(vel, acc, dt));
-    pos = {pos.x + d.x, pos.y + d.y, pos.z + d.z};
-    Q4 dq = delta_quat(om, dt, 1.f);
-    Q4 dqi = qinverse(dq);
-    V3 va{vel.x + dt * acc.x, vel.y + dt * acc.y, vel.z + dt * acc.z};
-    vel = qrot(dqi, va);
-    acc = qrot(dqi, acc);
-    quat = qmul(quat, dq);
-    out[0] = pos.x; out[1] = pos.y; out[2] = pos.z;
-    out[3] = quat.w; out[4] = quat.x; out[5] = quat.y; out[6] = quat.z;
-    out[7] = vel.x; out[8] = vel.y; out[9] = vel.z;
-    out[10] = last[10]; out[11] = last[11]; out[12] = last[12];
-    out[13] = acc.x; out[14] = acc.y; out[15] = acc.z;
-    for (int i = 16; i < EKF_BASE; i++) out[i] = last[i];
-}
-
-// The part of convolveFeature that depends on the base state only (:405-446): the inverse
-// frame rotation and the rotated translation are shared by all landmarks.
-struct BaseMotion {
-    Q4 dqi;
-    V3 rt;  // dq_inv * translation
-};
-__device__ inline BaseMotion base_motion(const float* base, float dt) {
-    V3 vel{base[7], base[8], base[9]};
-    V3 acc{base[13], base[14], base[15]};
-    V3 om{base[10], base[11], base[12]};
-    BaseMotion bm;
-    bm.dqi = delta_quat(om, dt, -1.f);
-    bm.rt = qrot(bm.dqi, translation(vel, acc, dt));
-    return bm;
-}
-// convolveFeature (:397-460) given the base-dependent part
-__device__ inline V3 convolve_feature(const BaseMotion& bm, float u, float v, float rho) {
-    V3 p;
-    p.z = (float)(1.0 / (double)rho);
-    p.x = u * p.z;
-    p.y = v * p.z;
-    V3 a = qrot(bm.dqi, p);
-    p = {a.x + (-bm.rt.x), a.y + (-bm.rt.y), a.z + (-bm.rt.z)};
-    p.x /= p.z;
-    p.y /= p.z;
-    p.z = (float)(1.0 / (double)p.z);
-    return p;
-}
-
-__device__ inline float plus_delta(float x) { return (float)((double)x + 1e-3); }
-__device__ inline float minus_2delta(float x) { return (float)((double)x - 2 * 1e-3); }
-__device__ inline float two_delta() { return (float)(2 * 1e-3); }
+#include "motion_model.inc"
 
 // ---------------------------------------------------------------------------------------
 // numericallyLinearizeProcess + mean propagation in one launch.
@@ -232,7 +113,6 @@ __device__ __forceinline__ void bookkeeping_body(const BookArgs& a) {
     if (tid <= EKF_BASE) a.inv_idx[tid == EKF_BASE ? EKF_BASE + 3 * N : tid] = -1;  // base state and the K*y column
 }
 
-#define LIN_LM 8
 __global__ __launch_bounds__(256) void linearize_kernel(const float* __restrict__ mu, int N, float dt, float* FA,
                                                         float* FB, float* FD, float* mu_next, BookArgs book) {
     // device-resident sequences: the measurement bookkeeping of the coming update rides along as one more
@@ -242,104 +122,8 @@ __global__ __launch_bounds__(256) void linearize_kernel(const float* __restrict_
         return;
     }
     const int base_block = (int)gridDim.x - 1 - (book.enabled ? 1 : 0);
-    __shared__ float s_base[EKF_BASE];
-    __shared__ BaseMotion s_bm[19];            // 0: unperturbed, 1+2c: col 7+c plus, 2+2c: minus
-    __shared__ float s_hi[16][EKF_BASE];       // base workgroup: convolveBaseState at +delta
-    __shared__ float s_lo[16][EKF_BASE];
-    __shared__ float s_res[LIN_LM][25][3];
-    const int tid = threadIdx.x;
-    if (tid < EKF_BASE) s_base[tid] = mu[tid];
-    __syncthreads();
-    const float td = two_delta();
-    if ((int)blockIdx.x == base_block) {
-        if (tid < 32) {
-            // 32 evaluations of convolveBaseState: column j = 0..15, high and low test points
-            const int j = tid >> 1;
-            float t[EKF_BASE], o[EKF_BASE];
-#pragma unroll
-            for (int i = 0; i < EKF_BASE; i++) t[i] = (i == j) ? plus_delta(s_base[i]) : s_base[i];
-            if (tid & 1) {
-#pragma unroll
-                for (int i = 0; i < EKF_BASE; i++) t[i] = (i == j) ? minus_2delta(t[i]) : t[i];
-            }
-            convolve_base(t, dt, o);
-#pragma unroll
-            for (int i = 0; i < EKF_BASE; i++) (tid & 1 ? s_lo : s_hi)[j][i] = o[i];
-        } else if (tid == 32) {
-            float o[EKF_BASE];
-            convolve_base(s_base, dt, o);
-#pragma unroll
-            for (int i = 0; i < EKF_BASE; i++) mu_next[i] = o[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < EKF_BASE * EKF_BASE; e += 256) {
-            const int j = e / EKF_BASE, i = e % EKF_BASE;
-            FA[e] = (j < 16) ? (s_hi[j][i] - s_lo[j][i]) / td : ((i == j) ? 1.f : 0.f);
-        }
-        return;
-    }
-    if (tid < 19) {
-        float t[EKF_BASE];
-#pragma unroll
-        for (int i = 0; i < EKF_BASE; i++) t[i] = s_base[i];
-        if (tid > 0) {
-            const int c = 7 + (tid - 1) / 2;
-#pragma unroll
-            for (int i = 7; i < 16; i++) {
-                if (i == c) {
-                    t[i] = plus_delta(t[i]);
-                    if (((tid - 1) & 1) == 1) t[i] = minus_2delta(t[i]);
-                }
-            }
-        }
-        s_bm[tid] = base_motion(t, dt);
-    }
-    __syncthreads();
-    const int lm = tid >> 5, e = tid & 31;
-    const int f = blockIdx.x * LIN_LM + lm;
-    const bool live = f < N;
-    float u = 0.f, v = 0.f, rho = 1.f;
-    if (live) {
-        u = mu[EKF_BASE + 3 * f];
-        v = mu[EKF_BASE + 3 * f + 1];
-        rho = mu[EKF_BASE + 3 * f + 2];
-    }
-    if (live && e < 25) {
-        V3 o;
-        if (e < 18) {
-            o = convolve_feature(s_bm[1 + e], u, v, rho);  // column 7 + e/2, plus (even) / minus (odd)  (:223-253)
-        } else if (e < 24) {
-            // the landmark's own 3x3 block (:262-321): component (e-18)/2, plus then minus
-            const int c = (e - 18) >> 1;
-            float t0 = u, t1 = v, t2 = rho;
-            if (c == 0) t0 = plus_delta(t0);
-            if (c == 1) t1 = plus_delta(t1);
-            if (c == 2) t2 = plus_delta(t2);
-            if (e & 1) {
-                if (c == 0) t0 = minus_2delta(t0);
-                if (c == 1) t1 = minus_2delta(t1);
-                if (c == 2) t2 = minus_2delta(t2);
-            }
-            o = convolve_feature(s_bm[0], t0, t1, t2);
-        } else {
-            o = convolve_feature(s_bm[0], u, v, rho);  // mean propagation with the OLD base state (:102-104)
-        }
-        s_res[lm][e][0] = o.x;
-        s_res[lm][e][1] = o.y;
-        s_res[lm][e][2] = o.z;
-    }
-    __syncthreads();
-    if (!live) return;
-    if (e < 12) {
-        // derivative column e: 0..8 -> state columns 7..15 (FB), 9..11 -> own block (FD)
-        float* o = (e < 9) ? (FB + (size_t)f * 27 + e * 3) : (FD + (size_t)f * 9 + (e - 9) * 3);
-#pragma unroll
-        for (int r = 0; r < 3; r++) o[r] = (s_res[lm][2 * e][r] - s_res[lm][2 * e + 1][r]) / td;
-    } else if (e == 24) {
-        mu_next[EKF_BASE + 3 * f] = s_res[lm][24][0];
-        mu_next[EKF_BASE + 3 * f + 1] = s_res[lm][24][1];
-        mu_next[EKF_BASE + 3 * f + 2] = s_res[lm][24][2];
-    }
+    __shared__ LinLds l;
+    linearize_block([mu](int e) { return mu[e]; }, N, dt, FA, FB, FD, mu_next, (int)blockIdx.x, base_block, l, (int)threadIdx.x);
 }
 
 // Scatter the Jacobian blocks into a dense n x n matrix (column-major, ld), zero elsewhere.
@@ -488,11 +272,11 @@ __global__ __launch_bounds__(256) void predict_fused_kernel(const float* __restr
     __shared__ float s_base[EKF_BASE];
     __shared__ BaseMotion s_bm[19];
     const float td = two_delta();
+    if (book.enabled && blockIdx.x == gridDim.x - 1) {  // (LIN, or a step whose linearisation ran inside the previous update's last GEMM)
+        bookkeeping_body<256>(book);
+        return;
+    }
     if (LIN) {
-        if (book.enabled && blockIdx.x == gridDim.x - 1) {
-            bookkeeping_body<256>(book);
-            return;
-        }
         if (tid < EKF_BASE) s_base[tid] = mu[tid];
     }
     if ((int)blockIdx.x < ntile) {
@@ -921,8 +705,12 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
     // (while the landmark tiles are a few rounds of workgroups: with thousands of tiles, N = 1024, the Jacobian blocks
     // formed 2 * 64 times over cost more than the launch they save)
     const int tiles_side = (f->N + PT - 1) / PT;
-    const bool lin_in_predict = f->cfg.predict_mode != EKFVIO_PREDICT_DENSE && f->fuse_linearize && tiles_side * tiles_side <= 4 * f->num_cus;
-    if (!lin_in_predict) launch_linearize(f, dt, book);
+    // round 6: the previous update's last GEMM has linearised for this step already (launch_update, GemmEpi::lin_blocks): FA / FB / FD and the
+    // propagated mean are in place, the propagation kernel only carries the bookkeeping along
+    const bool pre = f->prelinearized && f->cfg.predict_mode != EKFVIO_PREDICT_DENSE;
+    f->prelinearized = false;
+    const bool lin_in_predict = !pre && f->cfg.predict_mode != EKFVIO_PREDICT_DENSE && f->fuse_linearize && tiles_side * tiles_side <= 4 * f->num_cus;
+    if (!lin_in_predict && !pre) launch_linearize(f, dt, book);
     const int n = f->n, ld = f->ldp;
     dim3 grid((n + 255) / 256, n);
     if (f->cfg.predict_mode == EKFVIO_PREDICT_DENSE) {
@@ -941,12 +729,12 @@ void launch_predict(ekfvio_filter* f, float dt, const BookArgs* book) {
         const int ts = (f->N + PT - 1) / PT;
         const int chunks = (f->N + PC - 1) / PC;
         BookArgs b;
-        if (book && lin_in_predict) b = *book;
+        if (book && (lin_in_predict || pre)) b = *book;
         if (lin_in_predict)
             hipLaunchKernelGGL(predict_fused_kernel<true>, dim3(ts * ts + 1 + 2 * chunks + (b.enabled ? 1 : 0)), dim3(256), 0, f->stream,
                                f->P, ld, f->N, n, f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b, f->sweep_dbg);
         else
-            hipLaunchKernelGGL(predict_fused_kernel<false>, dim3(ts * ts + 1 + 2 * chunks), dim3(256), 0, f->stream, f->P, ld, f->N, n,
+            hipLaunchKernelGGL(predict_fused_kernel<false>, dim3(ts * ts + 1 + 2 * chunks + (b.enabled ? 1 : 0)), dim3(256), 0, f->stream, f->P, ld, f->N, n,
                                f->FA, f->FB, f->FD, dt, f->P2, ts, chunks, f->mu, f->mu_next, b, f->sweep_dbg);
         std::swap(f->P, f->P2);  // out of place; P2's padding is zero as well (never written outside n x n)
     }
@@ -1055,6 +843,18 @@ void launch_update(ekfvio_filter* f, int m, const float* d_z, const float* d_R, 
             e2.kyp_blocks = m_pad / 64;
             e2.kyp_ld = ld;
             e2.abort = f->sweep_abort_word;  // a persistent sweep that gave up: the GEMM writes nothing (T2, K, G' are scratch)
+            const int lin_blocks = (f->N + LIN_LM - 1) / LIN_LM + 1;
+            if (f->lin_next_dt >= 0.f && f->lin_overlap && f->cfg.predict_mode != EKFVIO_PREDICT_DENSE && f->fuse_linearize &&
+                gemm_single_round_with(f, n, n, m_pad, 1 + lin_blocks)) {
+                // a device-resident run (capture_steps): the next process(dt)'s linearisation and mean propagation ride in this launch, in workgroups
+                // of their own behind the tiles' (K y is final: the gain tiles' partial sums); launch_predict then only propagates Sigma
+                e2.lin_blocks = lin_blocks;
+                e2.lin_N = f->N;
+                e2.lin_dt = f->lin_next_dt;
+                e2.lin_FA = f->FA, e2.lin_FB = f->FB, e2.lin_FD = f->FD;
+                e2.lin_mu_next = f->mu_next;
+                f->prelinearized = true;
+            }
             launch_gemm(f, 1, n, n, m_pad, 1.f, f->Km, ld, f->Gm, ld, 1.f, t2_buffer(f), ld, f->P, ld, 1, 0, &e2);
         } else {
             if (!f->gain_in_sweep) launch_gain_from_sweep(f, f->Laug, m_pad, n_pad, lda, n, f->Km, f->Gm, ld, 0);

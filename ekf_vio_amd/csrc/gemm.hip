@@ -26,6 +26,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+namespace {
+#include "motion_model.inc"
+}  // namespace
+
 // Diagnostic cycle stamps (s_memtime) of one workgroup's wave 0 go to GemmEpi::stamps (per handle; null in production).
 #ifdef EKF_GEMM_STAMPS  // build with -DEKF_GEMM_STAMPS for scripts/gemm_stamps.py
 #define GSTAMP(i)                                                                                  \
@@ -442,9 +446,13 @@ __device__ __forceinline__ void gemm16_finish_mean(const GemmEpi& epi) {
     // do (round 6, profiles/r06_lin_pre_experiment.txt).
     int aborted = 0;
     if (epi.abort) aborted = *epi.abort;  // (an aborted persistent sweep in front: this update writes nothing)
+    // (mean_keep: the launch's linearising workgroups form mu + K y for themselves from the OLD mean -- nobody may write it under them -- and the
+    // propagation behind this launch replaces the state's mean anyway: launch_update)
+    const bool keep = EPI == 3 && epi.mean_keep;
     float v4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; u++) {
+        if (keep) break;
         const int e = min((int)threadIdx.x + 256 * u, epi.n - 1);
         if (EPI == 3) {
             // (the partial sums of up to 16 block columns as one batch from clamped addresses, added in block order afterwards: a loop with a
@@ -466,13 +474,13 @@ __device__ __forceinline__ void gemm16_finish_mean(const GemmEpi& epi) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int e = (int)threadIdx.x + 256 * u;
-        if (e < epi.n) {
+        if (e < epi.n && !keep) {
             if (EPI != 3) epi.Pcol[e] = 0.f;
             if (e >= 3 && e <= 6) s_q[e - 3] = v4[u];
             else epi.mu[e] = v4[u];
         }
     }
-    for (int e = threadIdx.x + 1024; e < epi.n; e += 256) {  // (not reached by the shapes this kernel is chosen for)
+    for (int e = threadIdx.x + 1024; e < (keep ? 0 : epi.n); e += 256) {  // (not reached by the shapes this kernel is chosen for)
         float v;
         if (EPI == 3) {
             float ky = epi.Kyp[e];
@@ -486,7 +494,7 @@ __device__ __forceinline__ void gemm16_finish_mean(const GemmEpi& epi) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): s_q written
     __builtin_amdgcn_s_barrier();        // (the workgroup's other wavefronts have returned)
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 4 && !keep) {
         const float qn = sqrtf(s_q[0] * s_q[0] + s_q[1] * s_q[1] + s_q[2] * s_q[2] + s_q[3] * s_q[3]);
         epi.mu[3 + threadIdx.x] = s_q[threadIdx.x] / qn;
     }
@@ -519,6 +527,45 @@ __global__ __launch_bounds__(256 * WPS) void gemm16_kernel(int M, int N, int K, 
     if ((EPI == 2 || EPI == 3) && (int)blockIdx.x == tiles_x * tiles_y) {
         if (threadIdx.x >= 256) return;
         if (epi.n > 0) gemm16_finish_mean<EPI>(epi);
+        return;
+    }
+    if (EPI == 3 && (int)blockIdx.x > tiles_x * tiles_y) {
+        // Round 6: the NEXT process(dt)'s linearisation and mean propagation (GemmEpi::lin_blocks), at the updated mean mu + K y with the quaternion
+        // renormalised -- formed here for the 22 + 3 LIN_LM elements this workgroup reads exactly as gemm16_finish_mean forms it (the same sums in the
+        // same order; one batch of loads) and never written back: the finishing workgroup leaves the mean alone in such a launch (mean_keep -- it
+        // would be writing under these workgroups' reads), and the propagation behind the launch replaces the state's mean.  Behind an aborted sweep
+        // the update is skipped: the linearisation is then taken at mu itself, as process(dt) would.
+        if (threadIdx.x >= 256) return;
+        const int tid = threadIdx.x;
+        const int lb = (int)blockIdx.x - tiles_x * tiles_y - 1;
+        LinLds& l = *reinterpret_cast<LinLds*>(&As[0][0]);
+        static_assert(sizeof(LinLds) <= sizeof(As), "linearisation scratch");
+        float* s_mu = &Bs[0][0];  // [22 + 3 LIN_LM]
+        int aborted = 0;
+        if (epi.abort) aborted = *epi.abort;
+        constexpr int NE = EKF_BASE + 3 * LIN_LM;
+        if (tid < NE) {
+            const int e = (tid < EKF_BASE) ? tid : min(EKF_BASE + 3 * LIN_LM * lb + (tid - EKF_BASE), epi.n - 1);
+            float pk[16];
+#pragma unroll
+            for (int cb = 0; cb < 16; cb++) pk[cb] = epi.Kyp[(size_t)min(cb, epi.kyp_blocks - 1) * epi.kyp_ld + e];
+            const float m0 = epi.mu[e];
+            float ky = pk[0];
+#pragma unroll
+            for (int cb = 1; cb < 16; cb++) ky = (cb < epi.kyp_blocks) ? ky + pk[cb] : ky;
+            for (int cb = 16; cb < epi.kyp_blocks; cb++) ky = ky + epi.Kyp[(size_t)cb * epi.kyp_ld + e];
+            s_mu[tid] = aborted ? m0 : m0 + ky;
+        }
+        __syncthreads();
+        if (tid < 4 && !aborted) {  // (one wavefront: every lane has read the four components before any of them writes)
+            const float qn = sqrtf(s_mu[3] * s_mu[3] + s_mu[4] * s_mu[4] + s_mu[5] * s_mu[5] + s_mu[6] * s_mu[6]);
+            const float qv = s_mu[3 + tid] / qn;
+            s_mu[3 + tid] = qv;
+        }
+        __syncthreads();
+        const int e0 = EKF_BASE + 3 * LIN_LM * lb;
+        auto mean = [s_mu, e0](int e) { return (e < EKF_BASE) ? s_mu[e] : s_mu[EKF_BASE + (e - e0)]; };
+        linearize_block(mean, epi.lin_N, epi.lin_dt, epi.lin_FA, epi.lin_FB, epi.lin_FD, epi.lin_mu_next, lb, epi.lin_blocks - 1, l, tid);
         return;
     }
     // XCD-aware tile order (bijective for any grid size)
@@ -832,6 +879,15 @@ bool gemm_throughput_regime(const ekfvio_filter* f, int M, int N, int K) {
     return !(K % 64 == 0 && ((M + 63) / 64) * ((N + 63) / 64) <= cus);
 }
 
+bool gemm_single_round_with(const ekfvio_filter* f, int M, int N, int K, int extra) {
+    if (K % 64 != 0) return false;
+    const int cus = f->num_cus > 0 ? f->num_cus : 256;
+    const int ty = (N + 63) / 64;
+    for (int bm : {32, 48, 64})
+        if (((M + bm - 1) / bm) * ty <= cus) return ((M + bm - 1) / bm) * ty + extra <= cus;
+    return false;
+}
+
 // cfg: 0 = choose by shape; 1 / 2 = the 64x64 kernel with 256 / 512 threads; 32, 48, 64 = gemm16_kernel with that BM
 // (512 threads); +100 = the same with 256 threads
 static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -861,7 +917,9 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         const int wps = cfg >= 100 ? 1 : 2;  // 132 / 148 / 164: one wavefront per SIMD (micro-benchmark only)
         const int bm = cfg % 100;
         const int tx = (M + bm - 1) / bm;
-        dim3 grid(tiles(bm) + ((e.mode == 2 || e.mode == 3) && e.n > 0 ? 1 : 0));  // (+1: gemm16_finish_mean)
+        if (!(e.mode == 3 && e.n > 0) || tiles(bm) + 1 + e.lin_blocks > cus) e.lin_blocks = 0;  // (launch_update asked gemm_single_round_with first)
+        e.mean_keep = e.lin_blocks > 0 ? 1 : 0;
+        dim3 grid(tiles(bm) + ((e.mode == 2 || e.mode == 3) && e.n > 0 ? 1 : 0) + e.lin_blocks);  // (+1: gemm16_finish_mean; + the next step's linearisation)
 #define GEMM16_GO(BMv, W, EP)                                                                                           \
     hipLaunchKernelGGL((gemm16_kernel<BMv, W, EP>), grid, dim3(256 * W), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, Cin, ldcin, C, \
                        ldc, flush, lowerB, e, tx, ty)
@@ -881,6 +939,7 @@ static void launch_gemm_cfg(ekfvio_filter* f, int cfg, int transB, int M, int N,
         return;
     }
     const int groups = cfg == 2 ? 2 : 1;
+    e.lin_blocks = 0, e.mean_keep = 0;  // (gemm16_kernel only)
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
     e.sym = (e.sym && e.mode == 2 && M == N && transB) ? 1 : 0;
     if (e.sym) {

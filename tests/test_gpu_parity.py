@@ -858,3 +858,38 @@ def test_replay_graphs_follow_the_number_of_live_handles():
     a.close()
     for k in ("base_mu", "feat_mu", "Sigma"):
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("N", [96, 256])
+def test_linearisation_inside_the_update_gemm_gives_the_per_call_bits(monkeypatch, N):
+    """Round 6.  Inside a device-resident run (ekfvio_run_uploaded: one captured graph of several steps) the next step's dt is
+    known, and in the T2 flow K y is final before the update's one GEMM: that launch carries the NEXT process(dt)'s numericallyLinearizeProcess
+    and mean propagation in workgroups of its own behind the tiles' (motion_model.inc: the same device functions, at mu + K y formed by the
+    same sums), and the covariance propagation behind it has only the strips left.  Same bits as one ekfvio_process + ekfvio_update per frame
+    (which linearises inside process(dt)), with and without it (EKFVIO_LIN_OVERLAP=0), including a frame with failed landmarks and across the
+    boundary between two captured graphs (40 frames = 32 + 8)."""
+    frames = 40
+    sc = Scenario(N, seed=6)
+    fr = list(sc.frames(frames))
+    z, R, p = (np.stack([f[i] for f in fr]) for i in range(3))
+    p = p.copy()
+    p[7, [1, N // 2]] = 0  # a ragged frame (the measured set is device data: the graph is the same)
+    states = {}
+    for mode in ("percall", "0", "1"):
+        if mode != "percall":
+            monkeypatch.setenv("EKFVIO_LIN_OVERLAP", mode)
+        g = TightlyCoupledEKF(max_features=N)
+        g.addNewFeatures(sc.initial_features())
+        if mode == "percall":
+            for i in range(frames):
+                g.process(sc.dt)
+                g.updateWithFeaturePositions(z[i], R[i], p[i])
+        else:
+            g.upload_measurements(z, R, p)
+            g.run_uploaded(0, frames, sc.dt)
+            g.synchronize()
+        states[mode] = g.get_state()
+        g.close()
+    for key in ("base_mu", "feat_mu", "last_klt", "del_flag", "Sigma"):
+        assert np.array_equal(states["0"][key], states["percall"][key]), key
+        assert np.array_equal(states["1"][key], states["percall"][key]), key
