@@ -541,7 +541,10 @@ def main():
                              "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                              "flops_per_launch": flops_per_launch, "avg_launch_us": avg_us,
-                             "shape": {"M": n, "N": n, "K": m_pad}}
+                             "shape": {"M": n, "N": n, "K": m_pad},
+                             "note": ("the product alone, replayed on scratch; inside the timed region's graphs the same launch also carries the NEXT step's "
+                                      "linearisation in 33 workgroups of its own (profiles/r06_linearisation_overlap.txt; rocprofv3 mean of the launch there: "
+                                      "profiles/r06_kernel_stats_n256.csv)") if t2_flow else "pairs replayed back to back on scratch"}
         # HBM-side traffic and MFMA-busy counters of the same kernels come from separate rocprofv3 --pmc passes
         # (bench.py cannot collect PMCs itself); the committed summaries are quoted when the workload matches
         for tag in (("r06",) if t2_flow else ("r05", "r04", "r03", "r02", "r01")):
